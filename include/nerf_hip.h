@@ -1,0 +1,173 @@
+/*
+ * nerf_hip.h -- C ABI of libnerf_hip.so: the MI355X (gfx950) kernels behind the per-ray
+ * render-and-train hot path of caseypeat/NeRF.
+ *
+ * The reference has no native code of its own: its hot path is Python (renderer.py, nets.py,
+ * helpers.py, trainer.py) calling stock ATen ops and the third-party CUDA package tinycudann.
+ * Each entry point below names the reference lines (relative to the reference checkout) whose
+ * arithmetic it replaces.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (PyTorch); the library allocates
+ *    nothing, keeps no pointer past return and never synchronises: it only enqueues work on
+ *    `stream` (a hipStream_t passed as void*; NULL = the null stream);
+ *  - tensors are contiguous row-major fp32 unless stated; indices are int64;
+ *  - return 0 on success, a negative NERF_E* code for an invalid argument, or a positive
+ *    hipError_t; nerf_last_error() gives the thread-local message;
+ *  - "nullable" outputs may be NULL and are then skipped.
+ */
+#ifndef NERF_HIP_H
+#define NERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NERF_ABI_VERSION 1
+#define NERF_MAX_LEVELS 32
+#define NERF_MAX_SEGMENTS 16
+#define NERF_MAX_SAMPLES 512 /* per-ray kernels keep one ray in LDS */
+
+#define NERF_EINVAL (-1)   /* null pointer / bad size */
+#define NERF_EUNSUPPORTED (-2) /* configuration outside what the fused kernels cover */
+
+/* Multiresolution hash grid geometry (tiny-cuda-nn "HashGrid" as configured at nets.py:39-50). */
+typedef struct NerfGridCfg {
+    int32_t n_levels;
+    int32_t n_features;        /* floats per table entry (1, 2 or 4) */
+    int32_t log2_hashmap_size;
+    int32_t base_resolution;
+    float scale[NERF_MAX_LEVELS];      /* pos = fma(x, scale, 0.5) */
+    uint32_t res[NERF_MAX_LEVELS];
+    uint32_t entries[NERF_MAX_LEVELS]; /* table entries of the level */
+    uint32_t hashed[NERF_MAX_LEVELS];  /* 1: spatial hash, 0: dense index */
+    uint64_t offset[NERF_MAX_LEVELS];  /* first entry of the level in the flat table */
+    uint64_t total_entries;
+} NerfGridCfg;
+
+/* Field network shape (nets.py:13-28 keyword arguments). */
+typedef struct NerfNetCfg {
+    int32_t hidden_dim;    /* sigma_hidden_dim == color_hidden_dim, must be 64 */
+    int32_t sigma_layers;  /* sigma_num_layers, >= 2 */
+    int32_t geo_feat_dim;  /* must be 15 (sigma net emits 16 rows) */
+    int32_t color_layers;  /* color_num_layers, >= 2 */
+    int32_t sh_degree;     /* encoding_dir_degree: 0, 2 or 4 */
+    int32_t latent_dim;    /* latent_embedding_dim, even, may be 0 */
+} NerfNetCfg;
+
+/* Where the sample points of a launch come from.
+ * mode 0 "points": x[M,3] are already contracted positions (what nets.py:109,148 receive),
+ *                  d[M,3] unit directions and n[M] image indices (field calls only).
+ * mode 1 "rays":   point (ray r, sample s) = rays_o[r] + rays_d[r] * z[r*z_stride + s]
+ *                  (renderer.py:51-61), contracted in-kernel (renderer.py:64-68), direction
+ *                  rays_d[r]/|rays_d[r]|, image index n[r]; z_stride = 0 shares one depth table. */
+typedef struct NerfPointSrc {
+    int32_t mode;
+    int32_t n_samples;        /* S (mode 1) */
+    int64_t n_points;         /* M = rays * S in mode 1 */
+    const float* x;
+    const float* d;
+    const int64_t* n;
+    const float* rays_o;
+    const float* rays_d;
+    const float* z;
+    int64_t z_stride;
+    float inner_bound;
+    float outer_bound;
+} NerfPointSrc;
+
+int nerf_abi_version(void);
+const char* nerf_last_error(void);
+
+/* Fill a NerfGridCfg from the encoding config (nets.py:41-48); returns total table entries. */
+int64_t nerf_grid_cfg_init(NerfGridCfg* cfg, int n_levels, int n_features, int log2_hashmap_size,
+                           int base_resolution, float per_level_scale);
+/* Floats of flat MLP parameters for the two networks (nets.py:53-63, 96-106), no biases. */
+int64_t nerf_sigma_param_count(const NerfGridCfg* grid, const NerfNetCfg* net);
+int64_t nerf_color_param_count(const NerfNetCfg* net);
+
+/* ---- ray generation and sample points: renderer.py:38-48 (get_rays) ---- */
+int nerf_raygen(const int64_t* h, const int64_t* w, const float* K /*[N,3,3]*/, const float* E /*[N,4,4]*/,
+                int64_t n_rays, float* rays_o /*[N,3]*/, float* rays_d /*[N,3]*/, void* stream);
+/* renderer.py:51-61 (get_sample_points) + :64-68 (mipnerf360_scale); all outputs nullable. */
+int nerf_sample_points(const float* rays_o, const float* rays_d, const float* z, int64_t z_stride, int64_t n_rays,
+                       int n_samples, float inner_bound, float outer_bound, float* xyz /*[N,S,3]*/,
+                       float* s_xyz /*[N,S,3]*/, float* dirs /*[N,3]*/, void* stream);
+/* renderer.py:64-68 on arbitrary points. */
+int nerf_contract(const float* xyz, int64_t n_points, float inner_bound, float outer_bound, float* out, void* stream);
+
+/* ---- encodings as stand-alone operators (what tcnn.Encoding does at nets.py:118,129,154) ---- */
+int nerf_hashgrid_fwd(const NerfGridCfg* grid, const float* table, const float* x01 /*[M,3]*/, int64_t n_points,
+                      float* out /*[M, L*F]*/, void* stream);
+int nerf_hashgrid_bwd(const NerfGridCfg* grid, const float* x01, const float* dout /*[M, L*F]*/, int64_t n_points,
+                      float* dtable /* accumulated into */, void* stream);
+int nerf_sh_fwd(const float* d01 /*[M,3] in [0,1]*/, int64_t n_points, int degree, float* out /*[M,degree^2]*/, void* stream);
+/* Bias-free MLP (tcnn.Network at nets.py:120,135,155): dims[0]=n_in, dims[n_layers]=n_out. */
+int nerf_mlp_fwd(const float* params, const int32_t* dims, int n_layers, const float* x, int64_t n_rows, float* out,
+                 void* stream);
+
+/* ---- fused field network ---- */
+/* NeRFNetwork.density (nets.py:148-164): normalise, hash-grid encode, sigma MLP, relu. */
+int nerf_density_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const float* table, const float* sigma_params,
+                     const NerfPointSrc* src, float* sigma /*[M]*/, float* x_hashtable /*[M,L*F] nullable*/, void* stream);
+/* NeRFNetwork.forward (nets.py:109-146). rgb [M,3]; xyz [M,3] (uncontracted, mode 1 only) nullable. */
+int nerf_field_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const float* table, const float* sigma_params,
+                   const float* color_params, const float* latent_emb /*[n_images, latent_dim]*/, int64_t n_images,
+                   const NerfPointSrc* src, float* sigma, float* rgb, float* x_hashtable /*nullable*/,
+                   float* xyz /*nullable*/, void* stream);
+/* Backward of nerf_field_fwd (what autograd + tcnn do under trainer.py:134).  Gradients are
+ * ACCUMULATED into dtable / dsigma_params / dcolor_params / dlatent (caller zeroes them). */
+int nerf_field_bwd(const NerfGridCfg* grid, const NerfNetCfg* net, const float* table, const float* sigma_params,
+                   const float* color_params, const float* latent_emb, int64_t n_images, const NerfPointSrc* src,
+                   const float* x_hashtable, const float* dsigma /*[M]*/, const float* drgb /*[M,3]*/,
+                   float* dtable, float* dsigma_params, float* dcolor_params, float* dlatent, void* stream);
+
+/* ---- hierarchical resampling ---- */
+/* renderer.py:154-160: alpha = 1-exp(-sigma*delta), exclusive transmittance, weights. zlog has
+ * row stride zlog_stride (0 = one shared [S] table). */
+int nerf_coarse_weights(const float* sigma, const float* zlog, int64_t zlog_stride, int64_t n_rays, int n_samples,
+                        float* weights, void* stream);
+/* renderer.py:132-142 (reweight_the_weights). */
+int nerf_reweight(const float* weights, int64_t n_rays, int n_samples, float alpha, const int32_t* steps, int n_segments,
+                  float* pdf, void* stream);
+/* renderer.py:87-118 (sample_pdf) + :165 (pow 10).  noise[N,Sf] replaces torch.rand of :102;
+ * lin[Sf] is torch.linspace(0, 1-1/Sf, Sf) from the host.  inds (int64) nullable; z_fine nullable. */
+int nerf_sample_pdf(const float* zlog, int64_t zlog_stride, const float* pdf, const float* noise, const float* lin,
+                    int64_t n_rays, int n_samples, int n_importance, float* zlog_fine, float* z_fine, int64_t* inds,
+                    void* stream);
+/* renderer.py:154-165 in one launch: sigma -> weights -> pdf -> fine depths. */
+int nerf_coarse_to_fine(const float* sigma, const float* zlog, int64_t zlog_stride, const float* noise, const float* lin,
+                        int64_t n_rays, int n_samples, int n_importance, float alpha, const int32_t* steps, int n_segments,
+                        float* zlog_fine, float* z_fine, void* stream);
+
+/* ---- alpha compositing: renderer.py:71-85 (render_rays_log) + :181-182 ---- */
+int nerf_composite_fwd(const float* sigma, const float* rgb, const float* z, const float* zlog, const float* bg /*[3]*/,
+                       int64_t n_rays, int n_samples, float zlog_lo, float zlog_range, float* image /*[N,3]*/,
+                       float* invdepth /*[N]*/, float* weights /*[N,S]*/, float* zlog_s /*[N,S] nullable*/, void* stream);
+/* d(loss)/d(sigma, rgb) from d(loss)/d(image, weights); dweights nullable (treated as 0). */
+int nerf_composite_bwd(const float* sigma, const float* rgb, const float* zlog, const float* bg, const float* dimage,
+                       const float* dweights, int64_t n_rays, int n_samples, float* dsigma, float* drgb, void* stream);
+
+/* ---- losses: helpers.py:21-32, trainer.py:153-169 ---- */
+/* sums[0..3] (double, zeroed by the call) receive loss_rgb, loss_dist, loss_depth, mse.
+ * dimage / dweights (nullable) receive grad_scale * d(loss_rgb + lam_dist*loss_dist + lam_depth*loss_depth).
+ * sorted != 0 asserts zlog_s rows are non-decreasing (O(S) distortion form), else O(S^2). */
+int nerf_losses(const float* image, const float* gt, const float* weights, const float* zlog_s, int64_t n_rays,
+                int n_samples, float lam_dist, float lam_depth, float grad_scale, int sorted, double* sums,
+                float* dimage, float* dweights, void* stream);
+
+/* ---- optimizer: torch.optim.Adam as configured at train.py:84-88 (dense, L2 weight decay) ---- */
+/* step is the 1-based step count; when zero_grad != 0 the gradient is cleared in the same pass. */
+int nerf_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t count, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int64_t step, float grad_scale, int zero_grad, void* stream);
+
+/* ---- inference helpers: inference.py:97-105 ---- */
+int nerf_cum_weights_thresh(const float* weights, int64_t n_rays, int n_samples, float thresh, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERF_HIP_H */

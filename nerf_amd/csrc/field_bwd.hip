@@ -1,0 +1,401 @@
+// Fused field-network backward for gfx950.  One 256-thread workgroup walks 128-point block
+// tiles; each of its 4 wavefronts re-runs the forward for its own 32 points from the saved
+// hash-grid features (x_hashtable), back-propagates through both MLPs with the same
+// register-resident MFMA chains as the forward (A operand = W^T read from the same LDS image),
+// scatters d(loss)/d(features) into the hash table with fp32 atomics and reduces the latent
+// gradient across the wavefront.  Weight gradients dW = dZ * H^T are summed over the 128 points
+// on the matrix cores too: each (dZ, H) pair is staged once through LDS as [unit][point], and
+// every wavefront owns a fixed subset of the 18 32x32 dW tiles in accumulators that persist
+// for the whole launch (one atomic flush per workgroup at the end).
+// Replaces autograd + tcnn backward under trainer.py:134.
+#include "field_common.h"
+
+int nerf_check_cfg(const char* fn, const NerfGridCfg* grid, const NerfNetCfg* net, bool with_color);
+int nerf_check_src(const char* fn, const NerfPointSrc* src, bool with_color);
+
+namespace {
+
+constexpr int kBlockPts = 128;
+constexpr int kSP = kBlockPts + 1;  // staging pitch (odd -> conflict-free row walks)
+constexpr int kSXP = 4 * 64 + 1;      // pitch of the per-lane gradient parking area
+
+// acc += SA[a_tile rows][:] * SB[b_tile rows][:]^T over the 128 staged points
+__device__ __forceinline__ f32x16 dw_tile(f32x16 acc, const float* SA, const float* SB, int a_tile, int b_tile, int n_out,
+                                          int n_in, int l31, int h) {
+    const int ar = a_tile * 32 + l31, br = b_tile * 32 + l31;
+    const bool al = ar < n_out, bl = br < n_in;
+    const float* pa = SA + (al ? ar : 0) * kSP + h;
+    const float* pb = SB + (bl ? br : 0) * kSP + h;
+#pragma unroll 16
+    for (int st = 0; st < kBlockPts / 2; ++st) {
+        const float a = al ? pa[2 * st] : 0.f;
+        const float b = bl ? pb[2 * st] : 0.f;
+        acc = MFMA32(a, b, acc);
+    }
+    return acc;
+}
+
+// stage a 64-row P-layout activation pair as [unit][point]
+__device__ __forceinline__ void stage64(float* S, int col, int h, const f32x16& v0, const f32x16& v1) {
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        S[(krow(t) + 4 * h) * kSP + col] = v0[t];
+        S[(32 + krow(t) + 4 * h) * kSP + col] = v1[t];
+    }
+}
+
+__device__ __forceinline__ void flush_tile(float* __restrict__ dw, const f32x16& acc, int a_tile, int b_tile, int n_out,
+                                           int n_in, int l31, int h) {
+    const int col = b_tile * 32 + l31;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int row = a_tile * 32 + krow(t) + 4 * h;
+        if (row < n_out && col < n_in) atomicAdd(dw + row * n_in + col, acc[t]);
+    }
+}
+
+__device__ __forceinline__ f32x16 relu_mask(const f32x16& d, const f32x16& act) {
+    f32x16 r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r[i] = act[i] > 0.f ? d[i] : 0.f;
+    return r;
+}
+
+template <int F>
+__global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, const float* __restrict__ sigma_w,
+                                                           const float* __restrict__ color_w,
+                                                           const float* __restrict__ latent, NerfPointSrc src,
+                                                           const float* __restrict__ xh, const float* __restrict__ dsigma,
+                                                           const float* __restrict__ drgb, float* __restrict__ dtable,
+                                                           float* __restrict__ dsw, float* __restrict__ dcw,
+                                                           float* __restrict__ dlatent, int sb_rows) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    lds_load_net(lds, s, sigma_w, color_w, true);
+    float* SA = lds + s.total;
+    float* SB = SA + kHid * kSP;
+    float* SX = SB + sb_rows * kSP;  // [LH*F][256 lanes]
+
+    const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = wave * 32 + l31;
+    const int64_t M = src.n_points;
+    const int64_t n_btiles = (M + kBlockPts - 1) / kBlockPts;
+    const int LF = g.L * F, LHF = g.LH * F;
+    const int in_c_tiles = (s.in_c + 31) / 32;
+
+    // persistent dW accumulators (roles depend on the wave, see the file comment)
+    f32x16 acc_s1 = zero16(), acc_c2 = zero16(), acc_c1 = zero16(), acc_x = zero16(), acc_y = zero16();
+    //   acc_s1: sigma layer 1 tile (wave>>1, wave&1)      acc_c2: colour layer 2 tile (wave>>1, wave&1)
+    //   acc_c1: colour layer 1 tile id = wave             acc_x : waves 0,1: colour layer 1 tile id 4+wave
+    //   acc_y : waves 0,1: sigma layer 2 tile (0, wave)            waves 2,3: colour layer 3 tile (0, wave-2)
+
+    for (int64_t bt = blockIdx.x; bt < n_btiles; bt += gridDim.x) {
+        const int64_t p_raw = bt * kBlockPts + col;
+        const bool valid = p_raw < M;
+        const int64_t p = valid ? p_raw : M - 1;
+        const PointIn q = fetch_point(src, p, true);
+        const float dsig = valid ? dsigma[p] : 0.f;
+        const float dr0 = valid ? drgb[p * 3] : 0.f, dr1 = valid ? drgb[p * 3 + 1] : 0.f, dr2 = valid ? drgb[p * 3 + 2] : 0.f;
+
+        // ------------------------- forward recompute -------------------------
+        f32x16 a0 = zero16(), a1 = zero16();
+        {
+            const float* w1r0 = lds + s.w_s1 + l31 * s.p_s1 + h * LHF;
+            const float* w1r1 = w1r0 + 32 * s.p_s1;
+            for (int j = 0; j < g.LH; ++j) {
+                const bool active = h ? (g.LH + j < g.L) : true;
+                const float* fp = xh + p * LF + (h * g.LH + j) * F;
+#pragma unroll
+                for (int f = 0; f < F; ++f) {
+                    const float b = active ? fp[f] : 0.f;
+                    a0 = MFMA32(w1r0[j * F + f], b, a0);
+                    a1 = MFMA32(w1r1[j * F + f], b, a1);
+                }
+            }
+        }
+        a0 = relu16(a0);
+        a1 = relu16(a1);
+        const f32x16 o2 = layer_64xN(lds + s.w_s2, s.p_s2, kGeoRows, l31, h, a0, a1);
+        f32x16 c0 = zero16(), c1 = zero16();
+        float sh[16];
+        sh16(q.dx, q.dy, q.dz, sh);
+        const float* lrow = latent + q.n * s.lat + h * s.lat_half;
+        {
+            const float* wc0 = lds + s.w_c1 + l31 * s.p_c1;
+            const float* wc1 = wc0 + 32 * s.p_c1;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int row = krow(t) + 4 * h;
+                const bool is_sigma = row == 0;
+                const int in = is_sigma ? 0 : row - 1;
+                const float b = is_sigma ? 0.f : o2[t];
+                c0 = MFMA32(wc0[in], b, c0);
+                c1 = MFMA32(wc1[in], b, c1);
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (t < s.sh_half) {
+                    float b = h ? sh[8 + t] : sh[t];
+                    if (s.sh_half == 2) b = h ? sh[2 + t] : sh[t];
+                    const int in = 15 + h * s.sh_half + t;
+                    c0 = MFMA32(wc0[in], b, c0);
+                    c1 = MFMA32(wc1[in], b, c1);
+                }
+            }
+            const int base = 15 + s.sh_dim + h * s.lat_half;
+#pragma unroll 4
+            for (int t = 0; t < s.lat_half; ++t) {
+                const float b = lrow[t];
+                c0 = MFMA32(wc0[base + t], b, c0);
+                c1 = MFMA32(wc1[base + t], b, c1);
+            }
+        }
+        c0 = relu16(c0);
+        c1 = relu16(c1);
+        f32x16 e0, e1;
+        layer_64x64(lds + s.w_c2, s.p_c2, l31, h, c0, c1, e0, e1);
+        e0 = relu16(e0);
+        e1 = relu16(e1);
+        const f32x16 o3 = layer_64xN(lds + s.w_c3, s.p_c3, 3, l31, h, e0, e1);
+
+        // ------------------------- colour layer 3 -------------------------
+        f32x16 d3 = zero16();
+        if (h == 0) {
+            const float r0 = 1.f / (1.f + expf(-o3[0])), r1 = 1.f / (1.f + expf(-o3[1])), r2 = 1.f / (1.f + expf(-o3[2]));
+            d3[0] = dr0 * r0 * (1.f - r0);
+            d3[1] = dr1 * r1 * (1.f - r1);
+            d3[2] = dr2 * r2 * (1.f - r2);
+        }
+        __syncthreads();  // previous iteration's readers of SA/SB are done
+        if (h == 0) {
+            SA[0 * kSP + col] = d3[0];
+            SA[1 * kSP + col] = d3[1];
+            SA[2 * kSP + col] = d3[2];
+        }
+        stage64(SB, col, h, e0, e1);
+        __syncthreads();
+        if (wave >= 2) acc_y = dw_tile(acc_y, SA, SB, 0, wave - 2, 3, kHid, l31, h);
+        f32x16 g0, g1;
+        layer_T_Nx64(lds + s.w_c3, s.p_c3, 3, l31, h, d3, g0, g1);
+        g0 = relu_mask(g0, e0);
+        g1 = relu_mask(g1, e1);
+        // ------------------------- colour layer 2 -------------------------
+        __syncthreads();
+        stage64(SA, col, h, g0, g1);
+        stage64(SB, col, h, c0, c1);
+        __syncthreads();
+        acc_c2 = dw_tile(acc_c2, SA, SB, wave >> 1, wave & 1, kHid, kHid, l31, h);
+        {
+            f32x16 t0, t1;
+            layer_T_64x64(lds + s.w_c2, s.p_c2, l31, h, g0, g1, t0, t1);
+            g0 = relu_mask(t0, c0);
+            g1 = relu_mask(t1, c1);
+        }
+        // ------------------------- colour layer 1 -------------------------
+        __syncthreads();
+        stage64(SA, col, h, g0, g1);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int row = krow(t) + 4 * h;
+            if (row >= 1) SB[(row - 1) * kSP + col] = o2[t];
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            if (t < s.sh_half) {
+                float b = h ? sh[8 + t] : sh[t];
+                if (s.sh_half == 2) b = h ? sh[2 + t] : sh[t];
+                SB[(15 + h * s.sh_half + t) * kSP + col] = b;
+            }
+        }
+        for (int t = 0; t < s.lat_half; ++t) SB[(15 + s.sh_dim + h * s.lat_half + t) * kSP + col] = lrow[t];
+        __syncthreads();
+        acc_c1 = dw_tile(acc_c1, SA, SB, wave / in_c_tiles, wave % in_c_tiles, kHid, s.in_c, l31, h);
+        if (wave < 2 && 4 + wave < 2 * in_c_tiles)
+            acc_x = dw_tile(acc_x, SA, SB, (4 + wave) / in_c_tiles, (4 + wave) % in_c_tiles, kHid, s.in_c, l31, h);
+        // d(colour input): tile G = [geo rows 0..15 | latent 0..15], tile L = latent 16..47
+        f32x16 dG = zero16(), dL = zero16();
+        {
+            const int lat0 = 15 + s.sh_dim;
+            const int inG = l31 < 16 ? l31 - 1 : lat0 + (l31 - 16);
+            const bool liveG = l31 < 16 ? (l31 >= 1) : (l31 - 16 < s.lat);
+            const int inL = lat0 + 16 + l31;
+            const bool liveL = 16 + l31 < s.lat;
+            const float* wG = lds + s.w_c1 + (liveG ? inG : 0);
+            const float* wL = lds + s.w_c1 + (liveL ? inL : 0);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int kk = (krow(t) + 4 * h) * s.p_c1;
+                dG = MFMA32(liveG ? wG[kk] : 0.f, g0[t], dG);
+                dL = MFMA32(liveL ? wL[kk] : 0.f, g0[t], dL);
+            }
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int kk = (32 + krow(t) + 4 * h) * s.p_c1;
+                dG = MFMA32(liveG ? wG[kk] : 0.f, g1[t], dG);
+                dL = MFMA32(liveL ? wL[kk] : 0.f, g1[t], dL);
+            }
+        }
+        // latent gradient: rows 16..31 of tile G are latent 0..15, tile L holds latent 16..47
+        if (s.lat > 0) {
+            const int64_t n0 = __shfl(q.n, 0, kWave);
+            const bool uniform = __all(q.n == n0);
+            if (uniform) {
+#pragma unroll
+                for (int t = 8; t < 16; ++t) {
+                    float v = dG[t];
+#pragma unroll
+                    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+                    const int li = krow(t) + 4 * h - 16;
+                    if (l31 == 0 && li < s.lat) atomicAdd(dlatent + n0 * s.lat + li, v);
+                }
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    float v = dL[t];
+#pragma unroll
+                    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+                    const int li = 16 + krow(t) + 4 * h;
+                    if (l31 == 0 && li < s.lat) atomicAdd(dlatent + n0 * s.lat + li, v);
+                }
+            } else if (valid) {
+#pragma unroll
+                for (int t = 8; t < 16; ++t) {
+                    const int li = krow(t) + 4 * h - 16;
+                    if (li < s.lat) atomicAdd(dlatent + q.n * s.lat + li, dG[t]);
+                }
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int li = 16 + krow(t) + 4 * h;
+                    if (li < s.lat) atomicAdd(dlatent + q.n * s.lat + li, dL[t]);
+                }
+            }
+        }
+        // ------------------------- sigma layer 2 -------------------------
+        f32x16 d2 = zero16();
+#pragma unroll
+        for (int t = 0; t < 8; ++t) d2[t] = dG[t];
+        if (h == 0) d2[0] = o2[0] > 0.f ? dsig : 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 8; ++t) SA[(krow(t) + 4 * h) * kSP + col] = d2[t];
+        stage64(SB, col, h, a0, a1);
+        __syncthreads();
+        if (wave < 2) acc_y = dw_tile(acc_y, SA, SB, 0, wave, kGeoRows, kHid, l31, h);
+        layer_T_Nx64(lds + s.w_s2, s.p_s2, kGeoRows, l31, h, d2, g0, g1);
+        g0 = relu_mask(g0, a0);
+        g1 = relu_mask(g1, a1);
+        // ------------------------- sigma layer 1 -------------------------
+        __syncthreads();
+        stage64(SA, col, h, g0, g1);
+        for (int j = 0; j < g.LH; ++j) {
+            const bool active = h ? (g.LH + j < g.L) : true;
+            const float* fp = xh + p * LF + (h * g.LH + j) * F;
+#pragma unroll
+            for (int f = 0; f < F; ++f) SB[(h * LHF + j * F + f) * kSP + col] = active ? fp[f] : 0.f;
+        }
+        __syncthreads();
+        acc_s1 = dw_tile(acc_s1, SA, SB, wave >> 1, wave & 1, kHid, s.in_sp, l31, h);
+        // d(features): row map chosen so that each lane receives the gradients of its OWN levels:
+        // register t of tile T <-> internal feature h*LHF + 16*T + t
+        f32x16 x0 = zero16(), x1 = zero16();
+        {
+            const int hh = (l31 >> 2) & 1, qq = (l31 & 3) + 4 * (l31 >> 3);
+            const bool live0 = qq < LHF, live1 = 16 + qq < LHF;
+            const float* w0 = lds + s.w_s1 + (live0 ? hh * LHF + qq : 0);
+            const float* w1 = lds + s.w_s1 + (live1 ? hh * LHF + 16 + qq : 0);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int kk = (krow(t) + 4 * h) * s.p_s1;
+                x0 = MFMA32(live0 ? w0[kk] : 0.f, g0[t], x0);
+                x1 = MFMA32(live1 ? w1[kk] : 0.f, g0[t], x1);
+            }
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int kk = (32 + krow(t) + 4 * h) * s.p_s1;
+                x0 = MFMA32(live0 ? w0[kk] : 0.f, g1[t], x0);
+                x1 = MFMA32(live1 ? w1[kk] : 0.f, g1[t], x1);
+            }
+        }
+        // ------------------------- hash-table scatter -------------------------
+        // park the feature gradients in this lane's own LDS column so the level loop can stay a
+        // runtime loop (no barrier: every lane reads back only what it wrote itself)
+        if (dtable) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                if (t < LHF) SX[t * kSXP + lane + 64 * wave] = x0[t];
+                if (16 + t < LHF) SX[(16 + t) * kSXP + lane + 64 * wave] = x1[t];
+            }
+            for (int j = 0; j < g.LH; ++j) {
+                const LevelP lp = level_params(g, j, h);
+                if (valid && lp.active) {
+                    const Corners c = level_corners(lp, q.x, q.y, q.z);
+#pragma unroll
+                    for (int f = 0; f < F; ++f) {
+                        const float gr = SX[(j * F + f) * kSXP + lane + 64 * wave];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) atomicAdd(dtable + (size_t)c.idx[k] * F + f, c.w[k] * gr);
+                    }
+                }
+            }
+        }
+    }
+
+    // ------------------------- flush the weight gradients -------------------------
+    float* d_s1 = dsw;
+    float* d_s2 = dsw + kHid * s.in_s;
+    float* d_c1 = dcw;
+    float* d_c2 = dcw + kHid * s.in_c;
+    float* d_c3 = d_c2 + kHid * kHid;
+    flush_tile(d_s1, acc_s1, wave >> 1, wave & 1, kHid, s.in_s, l31, h);
+    flush_tile(d_c2, acc_c2, wave >> 1, wave & 1, kHid, kHid, l31, h);
+    flush_tile(d_c1, acc_c1, wave / in_c_tiles, wave % in_c_tiles, kHid, s.in_c, l31, h);
+    if (wave < 2) {
+        if (4 + wave < 2 * in_c_tiles)
+            flush_tile(d_c1, acc_x, (4 + wave) / in_c_tiles, (4 + wave) % in_c_tiles, kHid, s.in_c, l31, h);
+        flush_tile(d_s2, acc_y, 0, wave, kGeoRows, kHid, l31, h);
+    } else {
+        flush_tile(d_c3, acc_y, 0, wave - 2, 3, kHid, l31, h);
+    }
+}
+
+}  // namespace
+
+extern "C" int nerf_field_bwd(const NerfGridCfg* grid, const NerfNetCfg* net, const float* table, const float* sigma_params,
+                              const float* color_params, const float* latent_emb, int64_t n_images, const NerfPointSrc* src,
+                              const float* x_hashtable, const float* dsigma, const float* drgb, float* dtable,
+                              float* dsigma_params, float* dcolor_params, float* dlatent, void* stream) {
+    (void)table;
+    int rc = nerf_check_cfg("nerf_field_bwd", grid, net, true);
+    if (rc) return rc;
+    rc = nerf_check_src("nerf_field_bwd", src, true);
+    if (rc) return rc;
+    NERF_REQUIRE(sigma_params && color_params && x_hashtable && dsigma && drgb && dsigma_params && dcolor_params,
+                 "null pointer");
+    NERF_REQUIRE(net->latent_dim == 0 || (latent_emb && dlatent && n_images > 0), "latent embedding missing");
+    if (src->n_points == 0) return 0;
+    const GridDev g = make_grid_dev(grid);
+    const NetLds s = make_net_lds(grid, net, true);
+    NERF_UNSUPPORTED(s.in_sp > 64, "more than 64 hash-grid features");
+    NERF_UNSUPPORTED(s.in_c > 96 || s.lat > 48, "colour-net input wider than 96 or latent wider than 48");
+    int sb_rows = s.in_sp > kHid ? s.in_sp : kHid;
+    if (s.in_c > sb_rows) sb_rows = s.in_c;
+    const int lds_bytes = (s.total + kHid * kSP + sb_rows * kSP + (s.in_sp / 2) * kSXP) * (int)sizeof(float);
+    NERF_UNSUPPORTED(lds_bytes > 160 * 1024, "network too large for LDS");
+    const int64_t n_btiles = ceil_div64(src->n_points, kBlockPts);
+    const unsigned nb = (unsigned)(n_btiles < kNumCU ? n_btiles : kNumCU);
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(FF)                                                                                                     \
+    do {                                                                                                               \
+        auto kern = field_bwd_kernel<FF>;                                                                              \
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);  \
+        if (e != hipSuccess) { nerf_set_error("field_bwd: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }  \
+        kern<<<nb, 256, lds_bytes, st>>>(g, s, sigma_params, color_params, latent_emb, *src, x_hashtable, dsigma, drgb, \
+                                         dtable, dsigma_params, dcolor_params, dlatent, sb_rows);                      \
+    } while (0)
+    switch (grid->n_features) {
+        case 1: LAUNCH(1); break;
+        case 2: LAUNCH(2); break;
+        default: LAUNCH(4); break;
+    }
+#undef LAUNCH
+    return nerf_launch_status("nerf_field_bwd");
+}

@@ -1,0 +1,334 @@
+// Device building blocks of the fused field network on gfx950:
+//   * multiresolution hash-grid gather (tiny-cuda-nn HashGrid semantics, nets.py:39-50),
+//   * the bias-free 64-wide MLPs as chains of v_mfma_f32_32x32x2_f32 (exact fp32: the result is
+//     bit-for-bit a k-ordered fmaf chain), weights resident in LDS, activations in registers.
+//
+// Register/lane layout ("P layout"): a wavefront owns a tile of 32 sample points.  Lane l holds
+// point (l & 31); the two 32-lane halves h = l >> 5 split the K dimension of every product.  An
+// MFMA D = A*B with A = W[out][k] (from LDS) and B = act[k][point] (from registers) leaves
+// D[out][point] with the point on the lane and out = (r&3) + 8*(r>>2) + 4*h in register r --
+// which is exactly the B operand of the next layer, so activations never leave the registers.
+#pragma once
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+constexpr int kHid = 64;
+constexpr int kGeoRows = 16;  // sigma net output rows: sigma + 15 geo features
+constexpr int kTilePts = 32;
+
+struct GridDev {
+    int L, F, LH;  // LH = ceil(L/2): levels handled by each lane half
+    float scale[NERF_MAX_LEVELS];
+    uint32_t res[NERF_MAX_LEVELS];
+    uint32_t entries[NERF_MAX_LEVELS];
+    uint32_t hashed[NERF_MAX_LEVELS];
+    uint32_t offset[NERF_MAX_LEVELS];
+};
+
+// LDS image of the network weights: every layer row-major [out][pitch] with an ODD pitch, which
+// makes both the forward read (lanes walk `out`) and the backward read (lanes walk `in`)
+// bank-conflict free for ds_read_b32.
+struct NetLds {
+    int in_s;    // L*F
+    int in_sp;   // 2*LH*F (internal, zero padded when L is odd)
+    int in_c;    // 15 + sh_dim + latent
+    int sh_dim, sh_half, lat, lat_half;
+    int w_s1, p_s1;  // [64][p_s1]
+    int w_s2, p_s2;  // [16][65]
+    int w_c1, p_c1;  // [64][p_c1]
+    int w_c2, p_c2;  // [64][65]
+    int w_c3, p_c3;  // [3][65]
+    int total;       // floats
+};
+
+static inline GridDev make_grid_dev(const NerfGridCfg* g) {
+    GridDev d = {};
+    d.L = g->n_levels;
+    d.F = g->n_features;
+    d.LH = (g->n_levels + 1) / 2;
+    for (int l = 0; l < g->n_levels; ++l) {
+        d.scale[l] = g->scale[l];
+        d.res[l] = g->res[l];
+        d.entries[l] = g->entries[l];
+        d.hashed[l] = g->hashed[l];
+        d.offset[l] = (uint32_t)g->offset[l];
+    }
+    return d;
+}
+
+static inline NetLds make_net_lds(const NerfGridCfg* g, const NerfNetCfg* n, bool with_color) {
+    NetLds s = {};
+    s.in_s = g->n_levels * g->n_features;
+    s.in_sp = 2 * ((g->n_levels + 1) / 2) * g->n_features;
+    s.sh_dim = n->sh_degree * n->sh_degree;
+    s.sh_half = s.sh_dim / 2;
+    s.lat = n->latent_dim;
+    s.lat_half = s.lat / 2;
+    s.in_c = n->geo_feat_dim + s.sh_dim + s.lat;
+    int off = 0;
+    s.w_s1 = off; s.p_s1 = s.in_sp | 1; off += kHid * s.p_s1;
+    s.w_s2 = off; s.p_s2 = kHid | 1;    off += kGeoRows * s.p_s2;
+    if (with_color) {
+        s.w_c1 = off; s.p_c1 = s.in_c | 1; off += kHid * s.p_c1;
+        s.w_c2 = off; s.p_c2 = kHid | 1;   off += kHid * s.p_c2;
+        s.w_c3 = off; s.p_c3 = kHid | 1;   off += 3 * s.p_c3;
+    }
+    s.total = off;
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------
+// device side
+// ------------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+
+__device__ __forceinline__ int krow(int t) { return (t & 3) + 8 * (t >> 2); }  // + 4*h: row of register t
+
+// copy one layer [out][in] from global into LDS [out][pitch] (pad columns stay zero)
+__device__ __forceinline__ void lds_load_layer(float* lds, int pitch, const float* __restrict__ w, int out, int in) {
+    for (int i = threadIdx.x; i < out * in; i += blockDim.x) {
+        int o = i / in, k = i - o * in;
+        lds[o * pitch + k] = w[i];
+    }
+}
+
+__device__ __forceinline__ void lds_load_net(float* lds, const NetLds& s, const float* __restrict__ sw,
+                                             const float* __restrict__ cw, bool with_color) {
+    for (int i = threadIdx.x; i < s.total; i += blockDim.x) lds[i] = 0.f;
+    __syncthreads();
+    lds_load_layer(lds + s.w_s1, s.p_s1, sw, kHid, s.in_s);
+    lds_load_layer(lds + s.w_s2, s.p_s2, sw + kHid * s.in_s, kGeoRows, kHid);
+    if (with_color) {
+        lds_load_layer(lds + s.w_c1, s.p_c1, cw, kHid, s.in_c);
+        lds_load_layer(lds + s.w_c2, s.p_c2, cw + kHid * s.in_c, kHid, kHid);
+        lds_load_layer(lds + s.w_c3, s.p_c3, cw + kHid * s.in_c + kHid * kHid, 3, kHid);
+    }
+    __syncthreads();
+}
+
+struct PointIn {
+    float x, y, z;     // normalised to [0,1]^3 (nets.py:117)
+    float ux, uy, uz;  // before contraction (aux['xyzs'], renderer.py:191)
+    float dx, dy, dz;  // unit view direction
+    int64_t n;         // image index
+};
+
+__device__ __forceinline__ PointIn fetch_point(const NerfPointSrc& s, int64_t p, bool want_dir) {
+    PointIn q;
+    float x, y, z;
+    q.dx = q.dy = q.dz = 0.f;
+    q.n = 0;
+    if (s.mode == 0) {
+        x = s.x[p * 3]; y = s.x[p * 3 + 1]; z = s.x[p * 3 + 2];
+        q.ux = x; q.uy = y; q.uz = z;
+        if (want_dir) {
+            q.dx = s.d[p * 3]; q.dy = s.d[p * 3 + 1]; q.dz = s.d[p * 3 + 2];
+            q.n = s.n ? s.n[p] : 0;
+        }
+    } else {
+        const int64_t r = (int64_t)((uint64_t)p / (uint32_t)s.n_samples);
+        const int smp = (int)(p - r * s.n_samples);
+        const float rx = s.rays_d[r * 3], ry = s.rays_d[r * 3 + 1], rz = s.rays_d[r * 3 + 2];
+        const float zv = s.z[r * s.z_stride + smp];
+        x = __fadd_rn(s.rays_o[r * 3], __fmul_rn(rx, zv));
+        y = __fadd_rn(s.rays_o[r * 3 + 1], __fmul_rn(ry, zv));
+        z = __fadd_rn(s.rays_o[r * 3 + 2], __fmul_rn(rz, zv));
+        q.ux = x; q.uy = y; q.uz = z;
+        const float rr = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z)));
+        if (rr > s.inner_bound) {  // renderer.py:64-68
+            const float sc = (s.outer_bound - (s.outer_bound - s.inner_bound) / rr) / rr;
+            x = __fmul_rn(x, sc); y = __fmul_rn(y, sc); z = __fmul_rn(z, sc);
+        }
+        if (want_dir) {
+            const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(rx, rx), __fmul_rn(ry, ry)), __fmul_rn(rz, rz)));
+            q.dx = rx / nrm; q.dy = ry / nrm; q.dz = rz / nrm;
+            q.n = s.n ? s.n[r] : 0;
+        }
+    }
+    const float two_ob = 2.f * s.outer_bound;
+    q.x = __fadd_rn(x, s.outer_bound) / two_ob;
+    q.y = __fadd_rn(y, s.outer_bound) / two_ob;
+    q.z = __fadd_rn(z, s.outer_bound) / two_ob;
+    return q;
+}
+
+struct LevelP {
+    float scale;
+    uint32_t res, entries, hashed, offset;
+    bool active;
+};
+
+// level handled by lane half h at step j: h*LH + j (inactive when past the last level)
+__device__ __forceinline__ LevelP level_params(const GridDev& g, int j, int h) {
+    const int l0 = j, l1 = min(g.LH + j, g.L - 1);
+    LevelP p;
+    p.scale = h ? g.scale[l1] : g.scale[l0];
+    p.res = h ? g.res[l1] : g.res[l0];
+    p.entries = h ? g.entries[l1] : g.entries[l0];
+    p.hashed = h ? g.hashed[l1] : g.hashed[l0];
+    p.offset = h ? g.offset[l1] : g.offset[l0];
+    p.active = h ? (g.LH + j < g.L) : true;
+    return p;
+}
+
+struct Corners {
+    uint32_t idx[8];
+    float w[8];
+};
+
+__device__ __forceinline__ Corners level_corners(const LevelP& lp, float x, float y, float z) {
+    const float px = fmaf(x, lp.scale, 0.5f), py = fmaf(y, lp.scale, 0.5f), pz = fmaf(z, lp.scale, 0.5f);
+    const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+    const float wx = px - fx, wy = py - fy, wz = pz - fz;
+    const uint32_t ix = (uint32_t)(int)fx, iy = (uint32_t)(int)fy, iz = (uint32_t)(int)fz;
+    const float ax[2] = {1.f - wx, wx}, ay[2] = {1.f - wy, wy}, az[2] = {1.f - wz, wz};
+    Corners c;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t cx = ix + (k & 1), cy = iy + ((k >> 1) & 1), cz = iz + ((k >> 2) & 1);
+        c.w[k] = __fmul_rn(__fmul_rn(ax[k & 1], ay[(k >> 1) & 1]), az[(k >> 2) & 1]);
+        uint32_t dense = cx + cy * lp.res + cz * (lp.res * lp.res);
+        if (dense >= lp.entries) dense %= lp.entries;
+        const uint32_t hash = (cx ^ (cy * 2654435761u) ^ (cz * 805459861u)) & (lp.entries - 1u);
+        c.idx[k] = lp.offset + (lp.hashed ? hash : dense);
+    }
+    return c;
+}
+
+template <int F>
+__device__ __forceinline__ void gather_level(const float* __restrict__ table, const Corners& c, float (&out)[F]) {
+    float v[8][F];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float* p = table + (size_t)c.idx[k] * F;
+        if (F == 1) v[k][0] = p[0];
+        if (F == 2) { f32x2 t = *(const f32x2*)p; v[k][0] = t.x; v[k][1] = t.y; }
+        if (F == 4) { f32x4 t = *(const f32x4*)p; v[k][0] = t.x; v[k][1] = t.y; v[k][2] = t.z; v[k][3] = t.w; }
+    }
+#pragma unroll
+    for (int f = 0; f < F; ++f) out[f] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int f = 0; f < F; ++f) out[f] = fmaf(c.w[k], v[k][f], out[f]);
+}
+
+// 16 real spherical harmonics of degree < 4 (tiny-cuda-nn SphericalHarmonics; input in [0,1])
+__device__ __forceinline__ void sh16(float d0, float d1, float d2, float (&o)[16]) {
+    const float x = (d0 + 1.f) / 2.f * 2.f - 1.f, y = (d1 + 1.f) / 2.f * 2.f - 1.f, z = (d2 + 1.f) / 2.f * 2.f - 1.f;
+    const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+    o[0] = 0.28209479177387814f;
+    o[1] = -0.48860251190291987f * y;
+    o[2] = 0.48860251190291987f * z;
+    o[3] = -0.48860251190291987f * x;
+    o[4] = 1.0925484305920792f * xy;
+    o[5] = -1.0925484305920792f * yz;
+    o[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+    o[7] = -1.0925484305920792f * xz;
+    o[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+    o[9] = 0.59004358992664352f * y * (-3.f * x2 + y2);
+    o[10] = 2.8906114426405538f * xy * z;
+    o[11] = 0.45704579946446572f * y * (1.f - 5.f * z2);
+    o[12] = 0.3731763325901154f * z * (5.f * z2 - 3.f);
+    o[13] = 0.45704579946446572f * x * (1.f - 5.f * z2);
+    o[14] = 1.4453057213202769f * z * (x2 - y2);
+    o[15] = 0.59004358992664352f * x * (-x2 + 3.f * y2);
+}
+
+__device__ __forceinline__ f32x16 relu16(f32x16 v) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], 0.f);
+    return v;
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 v;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = 0.f;
+    return v;
+}
+
+// out(64) = W[64][64] * in(64): forward through one hidden->hidden layer (P layout in and out)
+__device__ __forceinline__ void layer_64x64(const float* w, int pitch, int l31, int h, const f32x16& i0,
+                                            const f32x16& i1, f32x16& o0, f32x16& o1) {
+    const float* r0 = w + l31 * pitch + 4 * h;
+    const float* r1 = r0 + 32 * pitch;
+    o0 = zero16();
+    o1 = zero16();
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int k = krow(t);
+        o0 = MFMA32(r0[k], i0[t], o0);
+        o1 = MFMA32(r1[k], i0[t], o1);
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int k = 32 + krow(t);
+        o0 = MFMA32(r0[k], i1[t], o0);
+        o1 = MFMA32(r1[k], i1[t], o1);
+    }
+}
+
+// out(rows < n_out <= 32) = W[n_out][64] * in(64)
+__device__ __forceinline__ f32x16 layer_64xN(const float* w, int pitch, int n_out, int l31, int h, const f32x16& i0,
+                                             const f32x16& i1) {
+    const bool live = l31 < n_out;
+    const float* r0 = w + (live ? l31 : 0) * pitch + 4 * h;
+    f32x16 o = zero16();
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const float a = live ? r0[krow(t)] : 0.f;
+        o = MFMA32(a, i0[t], o);
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const float a = live ? r0[32 + krow(t)] : 0.f;
+        o = MFMA32(a, i1[t], o);
+    }
+    return o;
+}
+
+// d_in(64) = W^T * d_out where d_out has n_out (<= 32) live rows in P layout.
+__device__ __forceinline__ void layer_T_Nx64(const float* w, int pitch, int n_out, int l31, int h, const f32x16& d,
+                                             f32x16& o0, f32x16& o1) {
+    o0 = zero16();
+    o1 = zero16();
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        if (krow(t) < n_out) {  // compile-time after unrolling when n_out is a literal
+            const int k = krow(t) + 4 * h;
+            const bool live = k < n_out;
+            const float* r = w + (live ? k : 0) * pitch + l31;
+            const float a0 = live ? r[0] : 0.f, a1 = live ? r[32] : 0.f;
+            const float b = live ? d[t] : 0.f;
+            o0 = MFMA32(a0, b, o0);
+            o1 = MFMA32(a1, b, o1);
+        }
+    }
+}
+
+// d_in(64) = W[64][64]^T * d_out(64)
+__device__ __forceinline__ void layer_T_64x64(const float* w, int pitch, int l31, int h, const f32x16& d0,
+                                              const f32x16& d1, f32x16& o0, f32x16& o1) {
+    o0 = zero16();
+    o1 = zero16();
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const float* r = w + (krow(t) + 4 * h) * pitch + l31;
+        o0 = MFMA32(r[0], d0[t], o0);
+        o1 = MFMA32(r[32], d0[t], o1);
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const float* r = w + (32 + krow(t) + 4 * h) * pitch + l31;
+        o0 = MFMA32(r[0], d1[t], o0);
+        o1 = MFMA32(r[32], d1[t], o1);
+    }
+}
+
+#endif  // __HIPCC__

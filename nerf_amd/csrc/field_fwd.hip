@@ -1,0 +1,335 @@
+// Fused field-network forward for gfx950: hash-grid encoding feeding the sigma MLP (and, for the
+// full field, SH + latent + colour MLP) in one kernel.  The encoding is written straight into
+// the MFMA B operand of the first layer; weights stay in LDS, activations in registers.
+// Replaces NeRFNetwork.forward / .density (nets.py:109-164) and the tcnn objects they call.
+#include "field_common.h"
+
+namespace {
+
+// One wavefront = 32 points x 2 lane halves; lane half h gathers levels [h*LH, h*LH + LH).
+template <int F, bool COLOR>
+__global__ __launch_bounds__(256) void field_fwd_kernel(GridDev g, NetLds s, const float* __restrict__ table,
+                                                        const float* __restrict__ sigma_w,
+                                                        const float* __restrict__ color_w,
+                                                        const float* __restrict__ latent, NerfPointSrc src,
+                                                        float* __restrict__ sigma_out, float* __restrict__ rgb_out,
+                                                        float* __restrict__ xh_out, float* __restrict__ xyz_out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    lds_load_net(lds, s, sigma_w, color_w, COLOR);
+
+    const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = threadIdx.x >> 6, waves_per_block = blockDim.x >> 6;
+    const int64_t M = src.n_points;
+    const int64_t n_tiles = (M + kTilePts - 1) / kTilePts;
+    const int LF = g.L * F;
+
+    for (int64_t tile = (int64_t)blockIdx.x * waves_per_block + wave; tile < n_tiles;
+         tile += (int64_t)gridDim.x * waves_per_block) {
+        const int64_t p_raw = tile * kTilePts + l31;
+        const bool valid = p_raw < M;
+        const int64_t p = valid ? p_raw : M - 1;
+        const PointIn q = fetch_point(src, p, COLOR);
+
+        // ---- sigma layer 1: encode a level, feed its F features as the next F k-steps ----
+        f32x16 a0 = zero16(), a1 = zero16();
+        const float* w1r0 = lds + s.w_s1 + l31 * s.p_s1 + h * g.LH * F;
+        const float* w1r1 = w1r0 + 32 * s.p_s1;
+        for (int j = 0; j < g.LH; ++j) {
+            const LevelP lp = level_params(g, j, h);
+            const Corners c = level_corners(lp, q.x, q.y, q.z);
+            float feat[F];
+            gather_level<F>(table, c, feat);
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                const float b = lp.active ? feat[f] : 0.f;
+                a0 = MFMA32(w1r0[j * F + f], b, a0);
+                a1 = MFMA32(w1r1[j * F + f], b, a1);
+            }
+            if (xh_out && valid && lp.active) {
+                float* dst = xh_out + p * LF + (h * g.LH + j) * F;
+#pragma unroll
+                for (int f = 0; f < F; ++f) dst[f] = feat[f];
+            }
+        }
+        a0 = relu16(a0);
+        a1 = relu16(a1);
+        // ---- sigma layer 2: 64 -> 16 rows (row 0 = sigma, rows 1..15 = geo features) ----
+        const f32x16 o2 = layer_64xN(lds + s.w_s2, s.p_s2, kGeoRows, l31, h, a0, a1);
+        if (valid && h == 0) sigma_out[p] = fmaxf(o2[0], 0.f);
+        if (!COLOR) continue;
+
+        // ---- colour layer 1: inputs [geo(15) | SH | latent], K split between the halves ----
+        f32x16 c0 = zero16(), c1 = zero16();
+        const float* wc0 = lds + s.w_c1 + l31 * s.p_c1;
+        const float* wc1 = wc0 + 32 * s.p_c1;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {  // geo: register t holds sigma-net row krow(t) + 4h
+            const int row = krow(t) + 4 * h;
+            const bool is_sigma = row == 0;
+            const int in = is_sigma ? 0 : row - 1;
+            const float b = is_sigma ? 0.f : o2[t];
+            c0 = MFMA32(wc0[in], b, c0);
+            c1 = MFMA32(wc1[in], b, c1);
+        }
+        if (s.sh_dim > 0) {
+            float sh[16];
+            sh16(q.dx, q.dy, q.dz, sh);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (t < s.sh_half) {
+                    float b = h ? sh[8 + t] : sh[t];
+                    if (s.sh_half == 2) b = h ? sh[2 + t] : sh[t];
+                    const int in = 15 + h * s.sh_half + t;
+                    c0 = MFMA32(wc0[in], b, c0);
+                    c1 = MFMA32(wc1[in], b, c1);
+                }
+            }
+        }
+        {
+            const float* lrow = latent + q.n * s.lat + h * s.lat_half;
+            const int base = 15 + s.sh_dim + h * s.lat_half;
+#pragma unroll 4
+            for (int t = 0; t < s.lat_half; ++t) {
+                const float b = lrow[t];
+                c0 = MFMA32(wc0[base + t], b, c0);
+                c1 = MFMA32(wc1[base + t], b, c1);
+            }
+        }
+        c0 = relu16(c0);
+        c1 = relu16(c1);
+        f32x16 e0, e1;
+        layer_64x64(lds + s.w_c2, s.p_c2, l31, h, c0, c1, e0, e1);
+        e0 = relu16(e0);
+        e1 = relu16(e1);
+        const f32x16 o3 = layer_64xN(lds + s.w_c3, s.p_c3, 3, l31, h, e0, e1);
+        if (valid && h == 0) {
+            rgb_out[p * 3 + 0] = 1.f / (1.f + expf(-o3[0]));
+            rgb_out[p * 3 + 1] = 1.f / (1.f + expf(-o3[1]));
+            rgb_out[p * 3 + 2] = 1.f / (1.f + expf(-o3[2]));
+            if (xyz_out) {
+                xyz_out[p * 3 + 0] = q.ux;
+                xyz_out[p * 3 + 1] = q.uy;
+                xyz_out[p * 3 + 2] = q.uz;
+            }
+        }
+    }
+}
+
+// ---- stand-alone encodings (what tcnn.Encoding does when called on its own) ----
+template <int F>
+__global__ __launch_bounds__(256) void hashgrid_fwd_kernel(GridDev g, const float* __restrict__ table,
+                                                           const float* __restrict__ x01, int64_t M,
+                                                           float* __restrict__ out) {
+    // one thread per (point, level); consecutive threads walk the levels of one point
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * g.L) return;
+    const int64_t p = i / g.L;
+    const int l = (int)(i - p * g.L);
+    LevelP lp = {g.scale[l], g.res[l], g.entries[l], g.hashed[l], g.offset[l], true};
+    const Corners c = level_corners(lp, x01[p * 3], x01[p * 3 + 1], x01[p * 3 + 2]);
+    float feat[F];
+    gather_level<F>(table, c, feat);
+#pragma unroll
+    for (int f = 0; f < F; ++f) out[i * F + f] = feat[f];
+}
+
+template <int F>
+__global__ __launch_bounds__(256) void hashgrid_bwd_kernel(GridDev g, const float* __restrict__ x01,
+                                                           const float* __restrict__ dout, int64_t M,
+                                                           float* __restrict__ dtable) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * g.L) return;
+    const int64_t p = i / g.L;
+    const int l = (int)(i - p * g.L);
+    LevelP lp = {g.scale[l], g.res[l], g.entries[l], g.hashed[l], g.offset[l], true};
+    const Corners c = level_corners(lp, x01[p * 3], x01[p * 3 + 1], x01[p * 3 + 2]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int f = 0; f < F; ++f) atomicAdd(dtable + (size_t)c.idx[k] * F + f, c.w[k] * dout[i * F + f]);
+}
+
+__global__ void sh_fwd_kernel(const float* __restrict__ d01, int64_t M, int dim, float* __restrict__ out) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= M) return;
+    float sh[16];
+    // sh16 expects unit directions and re-applies the (d+1)/2 map; undo it here
+    sh16(d01[p * 3] * 2.f - 1.f, d01[p * 3 + 1] * 2.f - 1.f, d01[p * 3 + 2] * 2.f - 1.f, sh);
+    for (int k = 0; k < dim; ++k) out[p * dim + k] = sh[k];
+}
+
+// Generic bias-free MLP, one thread per row (stand-alone tcnn.Network calls; not the hot path).
+constexpr int kMlpMaxWidth = 128;
+struct Dims9 { int v[9]; };
+__global__ void mlp_fwd_kernel(const float* __restrict__ params, Dims9 d, int n_layers, const float* __restrict__ x,
+                               int64_t rows, float* __restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    float a[kMlpMaxWidth], b[kMlpMaxWidth];
+    const int n_in = d.v[0];
+    for (int k = 0; k < n_in; ++k) a[k] = x[r * n_in + k];
+    const float* w = params;
+    for (int l = 0; l < n_layers; ++l) {
+        const int in = d.v[l], o = d.v[l + 1];
+        for (int j = 0; j < o; ++j) {
+            float acc = 0.f;
+            for (int k = 0; k < in; ++k) acc = fmaf(w[j * in + k], a[k], acc);
+            b[j] = (l + 1 < n_layers) ? fmaxf(acc, 0.f) : acc;
+        }
+        for (int j = 0; j < o; ++j) a[j] = b[j];
+        w += in * o;
+    }
+    const int n_out = d.v[n_layers];
+    for (int j = 0; j < n_out; ++j) out[r * n_out + j] = a[j];
+}
+
+}  // namespace
+
+int nerf_check_cfg(const char* fn, const NerfGridCfg* grid, const NerfNetCfg* net, bool with_color) {
+    if (!grid || !net) { nerf_set_error("%s: null configuration", fn); return NERF_EINVAL; }
+    if (grid->n_levels < 1 || grid->n_levels > NERF_MAX_LEVELS || grid->total_entries >= (1ull << 32)) {
+        nerf_set_error("%s: bad grid configuration", fn); return NERF_EINVAL;
+    }
+    if (grid->n_features != 1 && grid->n_features != 2 && grid->n_features != 4) {
+        nerf_set_error("%s: unsupported: n_features_per_level must be 1, 2 or 4", fn); return NERF_EUNSUPPORTED;
+    }
+    if (net->hidden_dim != kHid || net->sigma_layers != 2 || net->geo_feat_dim != kGeoRows - 1) {
+        nerf_set_error("%s: unsupported: fused kernels need hidden_dim 64, sigma_num_layers 2, geo_feat_dim 15", fn);
+        return NERF_EUNSUPPORTED;
+    }
+    if (with_color && (net->color_layers != 3 || (net->sh_degree != 0 && net->sh_degree != 2 && net->sh_degree != 4) ||
+                       net->latent_dim < 0 || (net->latent_dim & 1))) {
+        nerf_set_error("%s: unsupported: fused kernels need color_num_layers 3, SH degree 0/2/4, even latent dim", fn);
+        return NERF_EUNSUPPORTED;
+    }
+    return 0;
+}
+
+int nerf_check_src(const char* fn, const NerfPointSrc* src, bool with_color) {
+    if (!src) { nerf_set_error("%s: null point source", fn); return NERF_EINVAL; }
+    if (src->n_points < 0) { nerf_set_error("%s: negative point count", fn); return NERF_EINVAL; }
+    if (src->mode == 0) {
+        if (!src->x || (with_color && !src->d)) { nerf_set_error("%s: points mode needs x (and d)", fn); return NERF_EINVAL; }
+    } else if (src->mode == 1) {
+        if (!src->rays_o || !src->rays_d || !src->z || src->n_samples < 1 || src->n_points % src->n_samples) {
+            nerf_set_error("%s: rays mode needs rays_o, rays_d, z and n_points = rays * n_samples", fn); return NERF_EINVAL;
+        }
+    } else { nerf_set_error("%s: unknown point-source mode", fn); return NERF_EINVAL; }
+    if (!(src->outer_bound > 0.f)) { nerf_set_error("%s: outer_bound must be positive", fn); return NERF_EINVAL; }
+    return 0;
+}
+
+static unsigned fwd_grid(int64_t n_points, int lds_bytes) {
+    const int64_t tiles = ceil_div64(n_points, kTilePts);
+    const int per_cu = lds_bytes > 0 ? (int)((160 * 1024) / lds_bytes) : 8;
+    const int64_t cap = (int64_t)kNumCU * (per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu));
+    const int64_t want = ceil_div64(tiles, 4);
+    return (unsigned)(want < cap ? want : cap);
+}
+
+template <bool COLOR>
+static int launch_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const float* table, const float* sw, const float* cw,
+                      const float* latent, const NerfPointSrc* src, float* sigma, float* rgb, float* xh, float* xyz,
+                      void* stream) {
+    const GridDev g = make_grid_dev(grid);
+    const NetLds s = make_net_lds(grid, net, COLOR);
+    const int lds_bytes = s.total * (int)sizeof(float);
+    const unsigned nb = fwd_grid(src->n_points, lds_bytes);
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(FF)                                                                                                     \
+    do {                                                                                                               \
+        auto kern = field_fwd_kernel<FF, COLOR>;                                                                       \
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);  \
+        if (e != hipSuccess) { nerf_set_error("field_fwd: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }  \
+        kern<<<nb, 256, lds_bytes, st>>>(g, s, table, sw, cw, latent, *src, sigma, rgb, xh, xyz);                      \
+    } while (0)
+    switch (grid->n_features) {
+        case 1: LAUNCH(1); break;
+        case 2: LAUNCH(2); break;
+        default: LAUNCH(4); break;
+    }
+#undef LAUNCH
+    return nerf_launch_status(COLOR ? "nerf_field_fwd" : "nerf_density_fwd");
+}
+
+extern "C" {
+
+int nerf_density_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const float* table, const float* sigma_params,
+                     const NerfPointSrc* src, float* sigma, float* x_hashtable, void* stream) {
+    int rc = nerf_check_cfg("nerf_density_fwd", grid, net, false);
+    if (rc) return rc;
+    rc = nerf_check_src("nerf_density_fwd", src, false);
+    if (rc) return rc;
+    NERF_REQUIRE(table && sigma_params && sigma, "null pointer");
+    if (src->n_points == 0) return 0;
+    return launch_fwd<false>(grid, net, table, sigma_params, nullptr, nullptr, src, sigma, nullptr, x_hashtable, nullptr, stream);
+}
+
+int nerf_field_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const float* table, const float* sigma_params,
+                   const float* color_params, const float* latent_emb, int64_t n_images, const NerfPointSrc* src,
+                   float* sigma, float* rgb, float* x_hashtable, float* xyz, void* stream) {
+    int rc = nerf_check_cfg("nerf_field_fwd", grid, net, true);
+    if (rc) return rc;
+    rc = nerf_check_src("nerf_field_fwd", src, true);
+    if (rc) return rc;
+    NERF_REQUIRE(table && sigma_params && color_params && sigma && rgb, "null pointer");
+    NERF_REQUIRE(net->latent_dim == 0 || (latent_emb && n_images > 0), "latent embedding missing");
+    if (src->n_points == 0) return 0;
+    return launch_fwd<true>(grid, net, table, sigma_params, color_params, latent_emb, src, sigma, rgb, x_hashtable, xyz, stream);
+}
+
+int nerf_hashgrid_fwd(const NerfGridCfg* grid, const float* table, const float* x01, int64_t n_points, float* out,
+                      void* stream) {
+    NERF_REQUIRE(grid && table && x01 && out, "null pointer");
+    NERF_REQUIRE(n_points >= 0 && grid->total_entries < (1ull << 32), "bad sizes");
+    if (n_points == 0) return 0;
+    const GridDev g = make_grid_dev(grid);
+    const unsigned nb = (unsigned)ceil_div64(n_points * g.L, 256);
+    hipStream_t st = (hipStream_t)stream;
+    switch (grid->n_features) {
+        case 1: hashgrid_fwd_kernel<1><<<nb, 256, 0, st>>>(g, table, x01, n_points, out); break;
+        case 2: hashgrid_fwd_kernel<2><<<nb, 256, 0, st>>>(g, table, x01, n_points, out); break;
+        case 4: hashgrid_fwd_kernel<4><<<nb, 256, 0, st>>>(g, table, x01, n_points, out); break;
+        default: nerf_set_error("nerf_hashgrid_fwd: unsupported n_features"); return NERF_EUNSUPPORTED;
+    }
+    return nerf_launch_status("nerf_hashgrid_fwd");
+}
+
+int nerf_hashgrid_bwd(const NerfGridCfg* grid, const float* x01, const float* dout, int64_t n_points, float* dtable,
+                      void* stream) {
+    NERF_REQUIRE(grid && x01 && dout && dtable, "null pointer");
+    NERF_REQUIRE(n_points >= 0 && grid->total_entries < (1ull << 32), "bad sizes");
+    if (n_points == 0) return 0;
+    const GridDev g = make_grid_dev(grid);
+    const unsigned nb = (unsigned)ceil_div64(n_points * g.L, 256);
+    hipStream_t st = (hipStream_t)stream;
+    switch (grid->n_features) {
+        case 1: hashgrid_bwd_kernel<1><<<nb, 256, 0, st>>>(g, x01, dout, n_points, dtable); break;
+        case 2: hashgrid_bwd_kernel<2><<<nb, 256, 0, st>>>(g, x01, dout, n_points, dtable); break;
+        case 4: hashgrid_bwd_kernel<4><<<nb, 256, 0, st>>>(g, x01, dout, n_points, dtable); break;
+        default: nerf_set_error("nerf_hashgrid_bwd: unsupported n_features"); return NERF_EUNSUPPORTED;
+    }
+    return nerf_launch_status("nerf_hashgrid_bwd");
+}
+
+int nerf_sh_fwd(const float* d01, int64_t n_points, int degree, float* out, void* stream) {
+    NERF_REQUIRE(d01 && out, "null pointer");
+    NERF_REQUIRE(degree >= 1 && degree <= 4 && n_points >= 0, "degree must be 1..4");
+    if (n_points == 0) return 0;
+    sh_fwd_kernel<<<(unsigned)ceil_div64(n_points, 256), 256, 0, (hipStream_t)stream>>>(d01, n_points, degree * degree, out);
+    return nerf_launch_status("nerf_sh_fwd");
+}
+
+int nerf_mlp_fwd(const float* params, const int32_t* dims, int n_layers, const float* x, int64_t n_rows, float* out,
+                 void* stream) {
+    NERF_REQUIRE(params && dims && x && out, "null pointer");
+    NERF_REQUIRE(n_layers >= 1 && n_layers <= 8 && n_rows >= 0, "bad sizes");
+    for (int i = 0; i <= n_layers; ++i) NERF_REQUIRE(dims[i] >= 1 && dims[i] <= kMlpMaxWidth, "layer width must be in [1,128]");
+    if (n_rows == 0) return 0;
+    Dims9 d = {};
+    for (int i = 0; i <= n_layers; ++i) d.v[i] = dims[i];
+    mlp_fwd_kernel<<<(unsigned)ceil_div64(n_rows, 64), 64, 0, (hipStream_t)stream>>>(params, d, n_layers, x, n_rows, out);
+    return nerf_launch_status("nerf_mlp_fwd");
+}
+
+}  // extern "C"
