@@ -1,0 +1,114 @@
+"""ctypes binding of libnerf_hip.so (include/nerf_hip.h).  No torch types cross the ABI:
+tensors are passed as raw device pointers plus sizes.  The library is REQUIRED: every product
+op raises if it is missing -- there is no CPU or eager-PyTorch fallback."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libnerf_hip.so')
+
+NERF_MAX_LEVELS = 32
+
+
+class NerfGridCfg(C.Structure):
+    _fields_ = [('n_levels', C.c_int32), ('n_features', C.c_int32), ('log2_hashmap_size', C.c_int32),
+                ('base_resolution', C.c_int32), ('scale', C.c_float * NERF_MAX_LEVELS),
+                ('res', C.c_uint32 * NERF_MAX_LEVELS), ('entries', C.c_uint32 * NERF_MAX_LEVELS),
+                ('hashed', C.c_uint32 * NERF_MAX_LEVELS), ('offset', C.c_uint64 * NERF_MAX_LEVELS),
+                ('total_entries', C.c_uint64)]
+
+
+class NerfNetCfg(C.Structure):
+    _fields_ = [('hidden_dim', C.c_int32), ('sigma_layers', C.c_int32), ('geo_feat_dim', C.c_int32),
+                ('color_layers', C.c_int32), ('sh_degree', C.c_int32), ('latent_dim', C.c_int32)]
+
+
+class NerfPointSrc(C.Structure):
+    _fields_ = [('mode', C.c_int32), ('n_samples', C.c_int32), ('n_points', C.c_int64), ('x', C.c_void_p),
+                ('d', C.c_void_p), ('n', C.c_void_p), ('rays_o', C.c_void_p), ('rays_d', C.c_void_p),
+                ('z', C.c_void_p), ('z_stride', C.c_int64), ('inner_bound', C.c_float), ('outer_bound', C.c_float)]
+
+
+_P, _I64, _I, _F = C.c_void_p, C.c_int64, C.c_int, C.c_float
+_G, _N, _S = C.POINTER(NerfGridCfg), C.POINTER(NerfNetCfg), C.POINTER(NerfPointSrc)
+
+# every symbol include/nerf_hip.h declares, with its argument types
+SIGNATURES = {
+    'nerf_abi_version': (C.c_int, []),
+    'nerf_last_error': (C.c_char_p, []),
+    'nerf_grid_cfg_init': (_I64, [_G, _I, _I, _I, _I, _F]),
+    'nerf_sigma_param_count': (_I64, [_G, _N]),
+    'nerf_color_param_count': (_I64, [_N]),
+    'nerf_raygen': (_I, [_P, _P, _P, _P, _I64, _P, _P, _P]),
+    'nerf_sample_points': (_I, [_P, _P, _P, _I64, _I64, _I, _F, _F, _P, _P, _P, _P]),
+    'nerf_contract': (_I, [_P, _I64, _F, _F, _P, _P]),
+    'nerf_hashgrid_fwd': (_I, [_G, _P, _P, _I64, _P, _P]),
+    'nerf_hashgrid_bwd': (_I, [_G, _P, _P, _I64, _P, _P]),
+    'nerf_sh_fwd': (_I, [_P, _I64, _I, _P, _P]),
+    'nerf_mlp_fwd': (_I, [_P, C.POINTER(C.c_int32), _I, _P, _I64, _P, _P]),
+    'nerf_density_fwd': (_I, [_G, _N, _P, _P, _S, _P, _P, _P]),
+    'nerf_field_fwd': (_I, [_G, _N, _P, _P, _P, _P, _I64, _S, _P, _P, _P, _P, _P]),
+    'nerf_field_bwd': (_I, [_G, _N, _P, _P, _P, _P, _I64, _S, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'nerf_coarse_weights': (_I, [_P, _P, _I64, _I64, _I, _P, _P]),
+    'nerf_reweight': (_I, [_P, _I64, _I, _F, C.POINTER(C.c_int32), _I, _P, _P]),
+    'nerf_sample_pdf': (_I, [_P, _I64, _P, _P, _P, _I64, _I, _I, _P, _P, _P, _P]),
+    'nerf_coarse_to_fine': (_I, [_P, _P, _I64, _P, _P, _I64, _I, _I, _F, C.POINTER(C.c_int32), _I, _P, _P, _P]),
+    'nerf_composite_fwd': (_I, [_P, _P, _P, _P, _P, _I64, _I, _F, _F, _P, _P, _P, _P, _P]),
+    'nerf_composite_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I64, _I, _P, _P, _P]),
+    'nerf_losses': (_I, [_P, _P, _P, _P, _I64, _I, _F, _F, _F, _I, _P, _P, _P, _P]),
+    'nerf_adam_step': (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _I64, _F, _I, _P]),
+    'nerf_cum_weights_thresh': (_I, [_P, _I64, _I, _F, _P, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libnerf_hip.so (once).  Raises if it has not been built: python __graft_entry__.py build."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError('libnerf_hip.so is missing (%s). Build it with `make -C nerf_amd/csrc`; '
+                               'nerf_amd has no fallback path.' % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        if l.nerf_abi_version() != 1:
+            raise RuntimeError('libnerf_hip.so ABI version mismatch')
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().nerf_last_error().decode()
+        if rc == -2:
+            raise NotImplementedError('%s: %s' % (what, msg))
+        raise RuntimeError('%s failed (%d): %s' % (what, rc, msg))
+
+
+def ptr(t):
+    """Device pointer of a contiguous CUDA/HIP tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError('nerf_amd kernels need tensors on the GPU (got %s); there is no CPU path' % t.device)
+    if not t.is_contiguous():
+        raise RuntimeError('nerf_amd kernels need contiguous tensors')
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def f32(t):
+    return t.contiguous() if t.dtype == torch.float32 else t.to(torch.float32).contiguous()
+
+
+def i64(t):
+    return t.contiguous() if t.dtype == torch.int64 else t.to(torch.int64).contiguous()

@@ -1,0 +1,116 @@
+"""Inferencer with the reference's surface (inference.py:27-223).  ``render_image`` keeps the
+chunk loop over ``n_rays`` but leaves every chunk on the GPU and copies the finished image to
+the host ONCE (the reference does a blocking .cpu() per chunk, inference.py:84-85).  Under
+torch.distributed each rank renders a contiguous slice of the flattened ray list and the slices
+are all_gathered once."""
+import numpy as np
+import torch
+
+from . import parallel
+from ._lib import check, f32, lib, ptr, stream
+
+
+class Inferencer(object):
+    def __init__(self, renderer, n_rays, image_num, rotate, max_variance_npy, max_variance_pcd, distribution_area, cams,
+                 freq):
+        self.renderer = renderer
+        self.n_rays = n_rays
+        self.image_num = image_num
+        self.rotate = rotate
+        self.max_variance_npy = max_variance_npy
+        self.max_variance_pcd = max_variance_pcd
+        self.distribution_area = distribution_area
+        self.cams = cams
+        self.freq = freq
+
+    def _flat(self, n, h, w, K, E):
+        n_f, h_f, w_f = torch.reshape(n, (-1,)), torch.reshape(h, (-1,)), torch.reshape(w, (-1,))
+        return n_f, h_f, w_f, torch.reshape(K, (-1, 3, 3)), torch.reshape(E, (-1, 4, 4))
+
+    def _chunks(self, total):
+        a0, b0 = parallel.shard_range(total, parallel.rank(), parallel.world_size())
+        for a in range(a0, b0, self.n_rays):
+            yield a, min(b0, a + self.n_rays)
+
+    def _white(self, device):
+        return torch.ones(3, device=device)   # fixed white background (inference.py:80)
+
+    @torch.no_grad()
+    def render_image(self, n, h, w, K, E, noise=None):
+        """inference.py:54-94."""
+        n_f, h_f, w_f, K_f, E_f = self._flat(n, h, w, K, E)
+        total = len(n_f)
+        dev = K_f.device
+        a0, b0 = parallel.shard_range(total, parallel.rank(), parallel.world_size())
+        image_l = torch.zeros((b0 - a0, 3), device=dev)
+        invdepth_l = torch.zeros((b0 - a0,), device=dev)
+        for a, b in self._chunks(total):
+            nz = None if noise is None else noise[a:b]
+            image_fb, _, _, aux = self.renderer.render(n_f[a:b], h_f[a:b], w_f[a:b], K_f[a:b], E_f[a:b],
+                                                       bg_color=self._white(dev), noise=nz)
+            image_l[a - a0:b - a0] = image_fb
+            invdepth_l[a - a0:b - a0] = aux['invdepth']
+        image_f = parallel.gather_slices(image_l, total)
+        invdepth_f = parallel.gather_slices(invdepth_l, total)
+        image = torch.reshape(image_f, (*h.shape, 3)).cpu().numpy()
+        invdepth = torch.reshape(invdepth_f, h.shape).cpu().numpy()
+        return image, invdepth
+
+    @torch.no_grad()
+    def calculate_cumlative_weights_thresh(self, weights, thresh):
+        """inference.py:97-105: one-hot of the first sample whose running weight sum reaches thresh."""
+        w = f32(weights)
+        out = torch.empty_like(w)
+        flat = w.reshape(-1, w.shape[-1])
+        check(lib().nerf_cum_weights_thresh(ptr(flat), flat.shape[0], flat.shape[1], thresh, ptr(out), stream()),
+              'nerf_cum_weights_thresh')
+        return out
+
+    def _thresh_depths(self, weights, z_vals):
+        ws = self.calculate_cumlative_weights_thresh(weights, 0.5 - self.distribution_area / 2)
+        wm = self.calculate_cumlative_weights_thresh(weights, 0.5)
+        we = self.calculate_cumlative_weights_thresh(weights, 0.5 + self.distribution_area / 2)
+        return (torch.sum(ws * z_vals, dim=-1), torch.sum(wm * z_vals, dim=-1), torch.sum(we * z_vals, dim=-1)), wm
+
+    @torch.no_grad()
+    def render_invdepth_thresh(self, n, h, w, K, E):
+        """inference.py:108-157."""
+        n_f, h_f, w_f, K_f, E_f = self._flat(n, h, w, K, E)
+        total = len(n_f)
+        dev = K_f.device
+        a0, b0 = parallel.shard_range(total, parallel.rank(), parallel.world_size())
+        out_l = torch.zeros((b0 - a0,), device=dev)
+        for a, b in self._chunks(total):
+            _, weights_fb, _, aux = self.renderer.render(n_f[a:b], h_f[a:b], w_f[a:b], K_f[a:b], E_f[a:b],
+                                                         bg_color=self._white(dev))
+            (d_start, d_mid, d_end), _ = self._thresh_depths(weights_fb, aux['z_vals'])
+            inv = 1 / d_mid
+            inv[torch.abs(d_start - d_end) > self.max_variance_pcd] = 0
+            inv[d_mid == 0] = 0
+            out_l[a - a0:b - a0] = inv
+        out_f = parallel.gather_slices(out_l, total)
+        return torch.reshape(out_f, h.shape).cpu().numpy()
+
+    @torch.no_grad()
+    def extract_surface_geometry(self, n, h, w, K, E):
+        """inference.py:160-223."""
+        n_f, h_f, w_f, K_f, E_f = self._flat(n, h, w, K, E)
+        total = len(n_f)
+        dev = K_f.device
+        points, colors, variance = [], [], []
+        for a, b in self._chunks(total):
+            _, weights_fb, _, aux = self.renderer.render(n_f[a:b].to(dev), h_f[a:b].to(dev), w_f[a:b].to(dev), K_f[a:b],
+                                                         E_f[a:b], bg_color=self._white(dev))
+            xyzs_fb, rgbs_fb, z_vals_fb = aux['xyzs'], aux['rgbs'], aux['z_vals']
+            (d_start, _, d_end), w_mid = self._thresh_depths(weights_fb, z_vals_fb)
+            dvar = torch.abs(d_start - d_end)[:, None].expand(-1, weights_fb.shape[1])
+            mask = (dvar < self.max_variance_npy) & w_mid.to(bool) & \
+                   (torch.linalg.norm(xyzs_fb, dim=-1) < self.renderer.inner_bound)
+            points.append(xyzs_fb[mask])
+            colors.append(rgbs_fb[mask])
+            variance.append(dvar[mask][:, None])
+        cat = lambda xs, c: torch.cat(xs, dim=0) if xs else torch.zeros((0, c), device=dev)
+        pts = parallel.gather_varlen(cat(points, 3))
+        col = parallel.gather_varlen(cat(colors, 3))
+        var = parallel.gather_varlen(cat(variance, 1))
+        return {'points': pts.cpu().numpy(), 'colors': col.cpu().numpy(), 'depth_variance': var.cpu().numpy()}

@@ -1,0 +1,113 @@
+"""Procedural synthetic scene exposing the batch interface of the reference's
+CameraGeometryLoader (loaders/camera_geometry_loader.py:91-152): ``get_random_batch``,
+``get_custom_batch``, ``get_image_batch``, ``get_pointcloud_batch``, ``get_calibration`` and the
+attributes ``images, N, H, W, depths_bool, translation_center``.
+
+Neither the Blender dataset of loaders/synthetic.py nor cv2 exists offline, so the scene is
+generated: V cameras on a sphere of radius 4.0311*0.8 (the Blender-synthetic convention after
+nerf_matrix_to_ngp's 0.8 scale, loaders/synthetic.py:24-32,60), 800x800, camera_angle_x 0.6911
+(loaders/synthetic.py:54-57), OpenCV axes (+z forward, as get_rays assumes).  Ground-truth RGBA
+images are optional (``render_images``): they are rendered once by the caller-provided field.
+
+Images and calibration live ON THE GPU and batches are sampled there: the reference's CPU
+randint + fancy-index + H2D copy per step (camera_geometry_loader.py:112-117) would dominate a
+sub-millisecond training step.
+"""
+import math
+
+import torch
+
+
+def sphere_cameras(n_img, seed=0, radius=4.0311 * 0.8, H=800, W=800, camera_angle_x=0.6911):
+    g = torch.Generator().manual_seed(seed)
+    az = torch.rand(n_img, generator=g) * 2 * math.pi
+    el = torch.rand(n_img, generator=g) * (math.pi / 2 - 0.2) + 0.1          # upper hemisphere
+    pos = radius * torch.stack([torch.cos(el) * torch.cos(az), torch.cos(el) * torch.sin(az), torch.sin(el)], -1)
+    fwd = -pos / pos.norm(dim=-1, keepdim=True)
+    up = torch.tensor([0.0, 0.0, 1.0]).expand_as(fwd)
+    right = torch.cross(fwd, up, dim=-1)
+    right = right / right.norm(dim=-1, keepdim=True)
+    down = torch.cross(fwd, right, dim=-1)
+    E = torch.zeros(n_img, 4, 4)
+    E[:, :3, 0], E[:, :3, 1], E[:, :3, 2], E[:, :3, 3] = right, down, fwd, pos
+    E[:, 3, 3] = 1
+    focal = 0.5 * W / math.tan(0.5 * camera_angle_x)
+    K = torch.zeros(n_img, 3, 3)
+    K[:, 0, 0] = focal
+    K[:, 1, 1] = focal
+    K[:, 0, 2] = W / 2
+    K[:, 1, 2] = H / 2
+    K[:, 2, 2] = 1
+    return K, E
+
+
+class ProceduralSceneLoader(object):
+    def __init__(self, n_images=100, H=800, W=800, seed=0, device='cuda', images=None, batch_seed=0):
+        self.N, self.H, self.W = n_images, H, W
+        self.device = device
+        K, E = sphere_cameras(n_images, seed, H=H, W=W)
+        self.intrinsics = K.to(device)
+        self.extrinsics = E.to(device)
+        self.translation_center = torch.zeros(1, 3, device=device)   # the sphere is centred on the origin
+        self.depths_bool = False
+        # uint8 RGBA like the reference store (camera_geometry_loader.py:41); white opaque until rendered
+        self.images = images if images is not None else None
+        self.generator = torch.Generator(device=device).manual_seed(batch_seed)
+
+    def set_images(self, images_u8):
+        assert images_u8.dtype == torch.uint8 and tuple(images_u8.shape) == (self.N, self.H, self.W, 4)
+        self.images = images_u8.to(self.device)
+
+    def format_groundtruth(self, gt, background=None):
+        """camera_geometry_loader.py:68-88."""
+        if background is None:
+            color_bg = torch.rand(3, device=gt.device, generator=self.generator)
+        else:
+            color_bg = torch.tensor(background, dtype=torch.float32, device=gt.device)
+        rgba = gt.to(torch.float32) / 255
+        rgb_gt = rgba[..., :3] * rgba[..., 3:] + color_bg * (1 - rgba[..., 3:])
+        return rgb_gt, color_bg
+
+    def get_custom_batch(self, n, h, w, background=None, device='cuda'):
+        """camera_geometry_loader.py:91-108."""
+        n, h, w = n.to(self.device), h.to(self.device), w.to(self.device)
+        K = self.intrinsics[n]
+        E = self.extrinsics[n].clone()
+        E[..., :3, 3] = E[..., :3, 3] - self.translation_center
+        if self.images is not None:
+            rgb_gt, color_bg = self.format_groundtruth(self.images[n, h, w, :], background)
+        else:   # no rendered ground truth: deterministic pseudo-colours (throughput runs)
+            color_bg = (torch.rand(3, device=self.device, generator=self.generator) if background is None
+                        else torch.tensor(background, dtype=torch.float32, device=self.device))
+            rgb_gt = torch.stack([(h % 256), (w % 256), ((h + w) % 256)], -1).to(torch.float32) / 255
+        return n, h, w, K, E, rgb_gt, color_bg, None
+
+    def get_random_batch(self, batch_size, device='cuda'):
+        """camera_geometry_loader.py:112-117, sampled on the GPU."""
+        n = torch.randint(0, self.N, (batch_size,), device=self.device, generator=self.generator)
+        h = torch.randint(0, self.H, (batch_size,), device=self.device, generator=self.generator)
+        w = torch.randint(0, self.W, (batch_size,), device=self.device, generator=self.generator)
+        return self.get_custom_batch(n, h, w)
+
+    def get_image_batch(self, image_num, device='cpu'):
+        """camera_geometry_loader.py:120-126."""
+        h = torch.arange(0, self.H, device=self.device)
+        w = torch.arange(0, self.W, device=self.device)
+        h, w = torch.meshgrid(h, w, indexing='ij')
+        n = torch.full(h.shape, fill_value=image_num, device=self.device)
+        return self.get_custom_batch(n, h, w, background=(1, 1, 1), device=device)
+
+    def get_pointcloud_batch(self, cams, freq, device='cpu'):
+        """camera_geometry_loader.py:129-143."""
+        idx = [i for i in range(self.N) if (i % 6 in cams) and (i // 6 % freq == 0)]
+        n = torch.tensor(idx, dtype=torch.int64, device=self.device)
+        h = torch.arange(0, self.H, device=self.device)
+        w = torch.arange(0, self.W, device=self.device)
+        n, h, w = torch.meshgrid(n, h, w, indexing='ij')
+        return self.get_custom_batch(n, h, w, background=(1, 1, 1), device=device)
+
+    def get_calibration(self, device='cuda'):
+        """camera_geometry_loader.py:146-152."""
+        E = self.extrinsics.clone()
+        E[..., :3, 3] = E[..., :3, 3] - self.translation_center
+        return self.N, self.H, self.W, self.intrinsics, E

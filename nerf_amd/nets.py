@@ -1,0 +1,256 @@
+"""Field network with the reference's surface (nets.py:12-164) on hand-written gfx950 kernels.
+
+``NeRFNetwork`` keeps the constructor arguments, the attribute names used to build optimizer
+groups (``encoder``, ``sigma_net``, ``encoder_dir``, ``color_net``, ``latent_emb``; train.py:85-87)
+and the ``forward`` / ``density`` signatures.  The tinycudann objects of the reference are
+replaced by small modules holding one flat fp32 ``params`` tensor each; the arithmetic runs in
+libnerf_hip.so (fused hash-grid gather + MFMA MLP chains), in fp32 throughout.
+"""
+import ctypes as C
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import NerfGridCfg, NerfNetCfg, NerfPointSrc, check, f32, i64, lib, ptr, stream
+
+
+def make_point_src(outer_bound, x=None, d=None, n=None, rays_o=None, rays_d=None, z=None, z_stride=0, n_samples=0,
+                   n_points=0, inner_bound=0.0):
+    s = NerfPointSrc()
+    s.mode = 0 if x is not None else 1
+    s.n_samples = int(n_samples)
+    s.n_points = int(n_points)
+    s.x, s.d, s.n = ptr(x), ptr(d), ptr(n)
+    s.rays_o, s.rays_d, s.z = ptr(rays_o), ptr(rays_d), ptr(z)
+    s.z_stride = int(z_stride)
+    s.inner_bound = float(inner_bound)
+    s.outer_bound = float(outer_bound)
+    return s
+
+
+class HashGridEncoding(nn.Module):
+    """tcnn.Encoding{HashGrid} (nets.py:39-50): flat fp32 table, base_resolution 16, scale 1.3819."""
+
+    def __init__(self, n_levels, n_features_per_level, log2_hashmap_size, base_resolution=16, per_level_scale=1.3819,
+                 device='cuda', seed=None):
+        super().__init__()
+        self.cfg = NerfGridCfg()
+        total = lib().nerf_grid_cfg_init(C.byref(self.cfg), n_levels, n_features_per_level, log2_hashmap_size,
+                                         base_resolution, per_level_scale)
+        if total < 0:
+            raise ValueError(lib().nerf_last_error().decode())
+        self.n_input_dims = 3
+        self.n_output_dims = n_levels * n_features_per_level
+        g = None
+        if seed is not None:
+            g = torch.Generator(device='cpu').manual_seed(seed)
+        init = (torch.rand(total * n_features_per_level, generator=g) * 2 - 1) * 1e-4
+        self.params = nn.Parameter(init.to(device))
+
+    def forward(self, x01):
+        return _HashGridFn.apply(x01, self.params, self)
+
+
+class _HashGridFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x01, params, enc):
+        x = f32(x01).reshape(-1, 3)
+        out = torch.empty(x.shape[0], enc.n_output_dims, device=x.device, dtype=torch.float32)
+        check(lib().nerf_hashgrid_fwd(C.byref(enc.cfg), ptr(params), ptr(x), x.shape[0], ptr(out), stream()),
+              'nerf_hashgrid_fwd')
+        ctx.save_for_backward(x)
+        ctx.enc = enc
+        ctx.n_params = params.numel()
+        return out.reshape(*x01.shape[:-1], enc.n_output_dims)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x,) = ctx.saved_tensors
+        dtable = torch.zeros(ctx.n_params, device=x.device, dtype=torch.float32)
+        d = f32(dout).reshape(-1, ctx.enc.n_output_dims)
+        check(lib().nerf_hashgrid_bwd(C.byref(ctx.enc.cfg), ptr(x), ptr(d), x.shape[0], ptr(dtable), stream()),
+              'nerf_hashgrid_bwd')
+        return None, dtable, None
+
+
+class SHEncoding(nn.Module):
+    """tcnn.Encoding{SphericalHarmonics} (nets.py:74-81): no parameters, input in [0,1]^3."""
+
+    def __init__(self, degree):
+        super().__init__()
+        self.degree = degree
+        self.n_output_dims = degree * degree
+        self.params = nn.Parameter(torch.zeros(0), requires_grad=False)
+
+    def forward(self, d01):
+        d = f32(d01).reshape(-1, 3)
+        out = torch.empty(d.shape[0], self.n_output_dims, device=d.device, dtype=torch.float32)
+        check(lib().nerf_sh_fwd(ptr(d), d.shape[0], self.degree, ptr(out), stream()), 'nerf_sh_fwd')
+        return out.reshape(*d01.shape[:-1], self.n_output_dims)
+
+
+class FullyFusedMLP(nn.Module):
+    """tcnn.Network{FullyFusedMLP} (nets.py:53-63, 96-106): bias-free, ReLU hidden, linear output,
+    one flat fp32 ``params`` ([out,in] row-major, layer after layer), Xavier-uniform init."""
+
+    def __init__(self, n_input_dims, n_output_dims, n_neurons, n_hidden_layers, device='cuda', seed=None):
+        super().__init__()
+        widths = [n_input_dims] + [n_neurons] * n_hidden_layers + [n_output_dims]
+        self.widths = widths
+        self.n_input_dims, self.n_output_dims = n_input_dims, n_output_dims
+        g = None
+        if seed is not None:
+            g = torch.Generator(device='cpu').manual_seed(seed)
+        chunks = []
+        for i in range(len(widths) - 1):
+            o, n = widths[i + 1], widths[i]
+            bound = math.sqrt(6.0 / (o + n))
+            chunks.append((torch.rand(o * n, generator=g) * 2 - 1) * bound)
+        self.params = nn.Parameter(torch.cat(chunks).to(device))
+
+    @torch.no_grad()
+    def forward(self, x):
+        """Stand-alone inference call (the training path goes through the fused field kernels)."""
+        xx = f32(x).reshape(-1, self.n_input_dims)
+        out = torch.empty(xx.shape[0], self.n_output_dims, device=xx.device, dtype=torch.float32)
+        dims = (C.c_int32 * len(self.widths))(*self.widths)
+        check(lib().nerf_mlp_fwd(ptr(self.params), dims, len(self.widths) - 1, ptr(xx), xx.shape[0], ptr(out), stream()),
+              'nerf_mlp_fwd')
+        return out.reshape(*x.shape[:-1], self.n_output_dims)
+
+
+class _FieldFn(torch.autograd.Function):
+    """sigma, rgb = field(points); backward = nerf_field_bwd (gradients for table, MLPs, latent)."""
+
+    @staticmethod
+    def forward(ctx, table, sigma_w, color_w, latent, net, src_kwargs, want_xyz):
+        src = make_point_src(**src_kwargs)
+        M = src.n_points
+        dev = table.device
+        sigma = torch.empty(M, device=dev, dtype=torch.float32)
+        rgb = torch.empty(M, 3, device=dev, dtype=torch.float32)
+        xh = torch.empty(M, net.encoder.n_output_dims, device=dev, dtype=torch.float32)
+        xyz = torch.empty(M, 3, device=dev, dtype=torch.float32) if want_xyz else None
+        lat = latent if latent is not None else None
+        check(lib().nerf_field_fwd(C.byref(net.encoder.cfg), C.byref(net.net_cfg), ptr(table), ptr(sigma_w), ptr(color_w),
+                                   ptr(lat), net.N, C.byref(src), ptr(sigma), ptr(rgb), ptr(xh), ptr(xyz), stream()),
+              'nerf_field_fwd')
+        ctx.net, ctx.src_kwargs = net, src_kwargs
+        ctx.save_for_backward(table, sigma_w, color_w, latent, xh)
+        ctx.mark_non_differentiable(xh)
+        if xyz is not None:
+            ctx.mark_non_differentiable(xyz)
+            return sigma, rgb, xh, xyz
+        return sigma, rgb, xh, None
+
+    @staticmethod
+    def backward(ctx, dsigma, drgb, _dxh, _dxyz):
+        table, sigma_w, color_w, latent, xh = ctx.saved_tensors
+        net = ctx.net
+        src = make_point_src(**ctx.src_kwargs)
+        dev = table.device
+        if dsigma is None:
+            dsigma = torch.zeros(src.n_points, device=dev)
+        if drgb is None:
+            drgb = torch.zeros(src.n_points, 3, device=dev)
+        # With direct gradients (FusedAdam.attach) the kernel accumulates straight into the tensors that
+        # param.grad aliases and autograd gets None; otherwise fresh zero-filled gradients are returned.
+        direct = net.direct_grads
+        if direct:
+            dtable, dsw, dcw = table.grad, sigma_w.grad, color_w.grad
+            dlat = latent.grad if latent is not None else None
+        else:
+            dtable, dsw, dcw = torch.zeros_like(table), torch.zeros_like(sigma_w), torch.zeros_like(color_w)
+            dlat = torch.zeros_like(latent) if latent is not None else None
+        check(lib().nerf_field_bwd(C.byref(net.encoder.cfg), C.byref(net.net_cfg), ptr(table), ptr(sigma_w), ptr(color_w),
+                                   ptr(latent), net.N, C.byref(src), ptr(xh), ptr(f32(dsigma)), ptr(f32(drgb)),
+                                   ptr(dtable), ptr(dsw), ptr(dcw), ptr(dlat), stream()), 'nerf_field_bwd')
+        if direct:
+            return None, None, None, None, None, None, None
+        return dtable, dsw, dcw, dlat, None, None, None
+
+
+class NeRFNetwork(nn.Module):
+    """Same constructor and call surface as the reference NeRFNetwork (nets.py:12-164)."""
+
+    def __init__(self, N, encoding_precision, encoding_n_levels, encoding_n_features_per_level,
+                 encoding_log2_hashmap_size, geo_feat_dim, sigma_hidden_dim, sigma_num_layers, encoding_dir_precision,
+                 encoding_dir_encoding, encoding_dir_degree, latent_embedding_dim, color_hidden_dim, color_num_layers,
+                 device='cuda', seed=None):
+        super().__init__()
+        lib()  # fail loudly, before any allocation, when the HIP library is missing
+        if encoding_precision not in ('float16', 'float32'):
+            raise ValueError('encoding_precision must be float16 or float32')   # nets.py:31-36
+        if encoding_dir_degree != 0 and encoding_dir_precision not in ('float16', 'float32'):
+            raise ValueError('encoding_dir_precision must be float16 or float32')   # nets.py:67-72
+        if encoding_dir_degree != 0 and encoding_dir_encoding != 'SphericalHarmonics':
+            raise NotImplementedError('only the SphericalHarmonics direction encoding is implemented')
+        # precision: the reference's fp16 switch only changes tcnn's storage type; this build computes in
+        # fp32 (the CPU/fp32 semantics are the parity spec), so both values run fp32.
+        self.encoding_precision = torch.float32
+        sd = (lambda k: None if seed is None else seed + k)
+        self.encoder = HashGridEncoding(encoding_n_levels, encoding_n_features_per_level, encoding_log2_hashmap_size,
+                                        device=device, seed=sd(0))
+        self.sigma_net = FullyFusedMLP(self.encoder.n_output_dims, 1 + geo_feat_dim, sigma_hidden_dim,
+                                       sigma_num_layers - 1, device=device, seed=sd(1))
+        if encoding_dir_degree != 0:
+            self.encoder_dir = SHEncoding(encoding_dir_degree)
+            self.directional_dim = self.encoder_dir.n_output_dims
+        else:
+            self.directional_dim = 0
+        self.N = N
+        self.latent_emb_dim = latent_embedding_dim          # (the reference's `latend_emb_dim` typo, nets.py:92, fixed)
+        if latent_embedding_dim != 0:
+            self.latent_emb = nn.Parameter(torch.zeros(N, latent_embedding_dim, device=device), requires_grad=True)
+        else:
+            self.latent_emb = None
+        self.in_dim_color = geo_feat_dim + self.directional_dim + self.latent_emb_dim
+        self.color_net = FullyFusedMLP(self.in_dim_color, 3, color_hidden_dim, color_num_layers - 1, device=device,
+                                       seed=sd(2))
+        if sigma_hidden_dim != color_hidden_dim:
+            raise NotImplementedError('fused kernels need sigma_hidden_dim == color_hidden_dim')
+        self.net_cfg = NerfNetCfg(sigma_hidden_dim, sigma_num_layers, geo_feat_dim, color_num_layers, encoding_dir_degree,
+                                  latent_embedding_dim)
+        self.direct_grads = False
+
+    # ---- gradient plumbing --------------------------------------------------------------
+    def enable_direct_grads(self, on=True):
+        """When on, every parameter must already own a persistent ``.grad`` tensor (FusedAdam.attach does
+        that); the backward kernel then accumulates into it in place and skips autograd's copies."""
+        if on:
+            for p in (self.encoder.params, self.sigma_net.params, self.color_net.params, self.latent_emb):
+                if p is not None and p.grad is None:
+                    p.grad = torch.zeros_like(p)
+        self.direct_grads = bool(on)
+
+    # ---- reference surface ----------------------------------------------------------------
+    def _field(self, src_kwargs, want_xyz=False):
+        return _FieldFn.apply(self.encoder.params, self.sigma_net.params, self.color_net.params, self.latent_emb, self,
+                              src_kwargs, want_xyz)
+
+    def forward(self, x, d, n, outer_bound):
+        """nets.py:109-146.  x: contracted points [...,3], d: unit dirs [...,3], n: image index [...]."""
+        prefix = x.shape[:-1]
+        xx, dd, nn_ = f32(x).reshape(-1, 3), f32(d).reshape(-1, 3), i64(n).reshape(-1)
+        sigma, rgb, xh, _ = self._field(dict(outer_bound=outer_bound, x=xx, d=dd, n=nn_, n_points=xx.shape[0]))
+        return sigma.reshape(*prefix), rgb.reshape(*prefix, 3), {'x_hashtable': xh.reshape(*prefix, -1).detach()}
+
+    @torch.no_grad()
+    def density(self, x, outer_bound):
+        """nets.py:148-164 (only ever called without grad: renderer.py:145,152)."""
+        prefix = x.shape[:-1]
+        xx = f32(x).reshape(-1, 3)
+        sigma, xh = self.density_src(make_point_src(outer_bound, x=xx, n_points=xx.shape[0]), want_features=True)
+        return sigma.reshape(*prefix), {'x_hashtable': xh.reshape(*prefix, -1)}
+
+    @torch.no_grad()
+    def density_src(self, src, want_features=False):
+        dev = self.encoder.params.device
+        sigma = torch.empty(src.n_points, device=dev, dtype=torch.float32)
+        xh = torch.empty(src.n_points, self.encoder.n_output_dims, device=dev) if want_features else None
+        check(lib().nerf_density_fwd(C.byref(self.encoder.cfg), C.byref(self.net_cfg), ptr(self.encoder.params),
+                                     ptr(self.sigma_net.params), C.byref(src), ptr(sigma), ptr(xh), stream()),
+              'nerf_density_fwd')
+        return sigma, xh

@@ -1,0 +1,93 @@
+"""Multi-GPU plumbing: one process per GPU, torch.distributed over RCCL (backend "nccl" on ROCm)
+for GPUs, gloo for the CPU logic tests.  The reference has no distributed code at all; the
+partitioning follows the natural shard axes of the path:
+
+  training   rays are independent, the loss is a mean over rays -> every rank draws its own ray
+             batch (seed = base + rank), all ranks hold a full parameter replica, gradients are
+             SUMMED by one all-reduce per tensor and scaled by 1/world inside the Adam kernel;
+  inference  pixels are independent -> contiguous slices of the flattened ray list, one
+             all_gather of the finished slices;
+  extraction voxels are independent -> contiguous slabs of the voxel index range, one
+             variable-length all_gather.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_initialized() else 0
+
+
+def shard_range(total, rank_, world):
+    """Contiguous [start, stop) slice of `total` items for `rank_`; sizes differ by at most one."""
+    base, rem = divmod(total, world)
+    start = rank_ * base + min(rank_, rem)
+    return start, start + base + (1 if rank_ < rem else 0)
+
+
+def all_reduce_grads(params, async_op=False):
+    """SUM-all-reduce the .grad of every parameter (largest first so the big transfer starts early).
+    Returns the list of work handles when async_op."""
+    if world_size() == 1:
+        return []
+    handles = []
+    for p in sorted((p for p in params if p is not None and p.grad is not None), key=lambda t: -t.numel()):
+        h = dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=async_op)
+        if async_op:
+            handles.append(h)
+    return handles
+
+
+def gather_slices(local, total, dim=0):
+    """all_gather contiguous slices produced with shard_range back into one tensor of length `total`."""
+    world = world_size()
+    if world == 1:
+        return local
+    sizes = [shard_range(total, r, world) for r in range(world)]
+    maxlen = max(b - a for a, b in sizes)
+    pad_shape = list(local.shape)
+    pad_shape[dim] = maxlen
+    padded = local.new_zeros(pad_shape)
+    padded.narrow(dim, 0, local.shape[dim]).copy_(local)
+    bufs = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(bufs, padded)
+    return torch.cat([b.narrow(dim, 0, e - s) for b, (s, e) in zip(bufs, sizes)], dim=dim)
+
+
+def gather_varlen(local):
+    """all_gather of [P_r, C] tensors with per-rank row counts (dense extraction results)."""
+    world = world_size()
+    if world == 1:
+        return local
+    count = torch.tensor([local.shape[0]], device=local.device, dtype=torch.int64)
+    counts = [torch.zeros_like(count) for _ in range(world)]
+    dist.all_gather(counts, count)
+    counts = [int(c.item()) for c in counts]
+    maxlen = max(max(counts), 1)
+    padded = local.new_zeros((maxlen,) + tuple(local.shape[1:]))
+    padded[:local.shape[0]] = local
+    bufs = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(bufs, padded)
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)

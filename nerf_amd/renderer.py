@@ -1,0 +1,238 @@
+"""Renderer with the reference's surface (renderer.py:10-194) on gfx950 kernels.
+
+Every method of the reference ``NerfRenderer`` is here with the same name, argument order and
+return values; each one is a thin host wrapper around a kernel of libnerf_hip.so.  ``render``
+and ``efficient_sampling`` take the fused route when the model is this package's
+``NeRFNetwork`` (ray -> sample point -> contraction -> hash grid -> MLP in one launch, no
+[N,S,3] intermediates); with any other model object (e.g. an analytic stub) they fall back to
+the method-by-method route, which still runs every renderer stage in HIP.
+
+Additive, optional arguments only: ``noise`` (the stratification noise of renderer.py:102,
+injected for bit-exact index parity) and ``generator``.
+"""
+import ctypes as C
+import math as m
+
+import torch
+import torch.nn as nn
+
+from ._lib import check, f32, i64, lib, ptr, stream
+from .nets import NeRFNetwork, make_point_src
+
+
+class _CompositeFn(torch.autograd.Function):
+    """renderer.py:71-85 + :181-182 as one kernel, with its hand-written backward."""
+
+    @staticmethod
+    def forward(ctx, sigmas, rgbs, z_vals, z_vals_log, bg, lo, rng):
+        sig, rgb, z, zl, bgc = f32(sigmas), f32(rgbs), f32(z_vals), f32(z_vals_log), f32(bg)
+        N, S = sig.shape
+        dev = sig.device
+        image = torch.empty(N, 3, device=dev)
+        invdepth = torch.empty(N, device=dev)
+        weights = torch.empty(N, S, device=dev)
+        zlog_s = torch.empty(N, S, device=dev)
+        check(lib().nerf_composite_fwd(ptr(sig), ptr(rgb), ptr(z), ptr(zl), ptr(bgc), N, S, lo, rng, ptr(image),
+                                       ptr(invdepth), ptr(weights), ptr(zlog_s), stream()), 'nerf_composite_fwd')
+        ctx.save_for_backward(sig, rgb, zl, bgc)
+        ctx.mark_non_differentiable(invdepth, zlog_s)
+        return image, invdepth, weights, zlog_s
+
+    @staticmethod
+    def backward(ctx, dimage, _dinv, dweights, _dzs):
+        sig, rgb, zl, bgc = ctx.saved_tensors
+        N, S = sig.shape
+        if dimage is None:
+            dimage = torch.zeros(N, 3, device=sig.device)
+        dsig = torch.empty_like(sig)
+        drgb = torch.empty_like(rgb)
+        dw = f32(dweights) if dweights is not None else None
+        check(lib().nerf_composite_bwd(ptr(sig), ptr(rgb), ptr(zl), ptr(bgc), ptr(f32(dimage)), ptr(dw), N, S, ptr(dsig),
+                                       ptr(drgb), stream()), 'nerf_composite_bwd')
+        return dsig, drgb, None, None, None, None, None
+
+
+class NerfRenderer(nn.Module):
+    def __init__(self, model, inner_bound, outer_bound, z_bounds, steps_firstpass, steps_importance, alpha_importance):
+        super().__init__()
+        lib()
+        self.model = model
+        self.inner_bound = inner_bound
+        self.outer_bound = outer_bound
+        self.z_bounds = list(z_bounds)
+        self.steps_firstpass = list(steps_firstpass)
+        self.steps_importance = steps_importance
+        self.alpha_importance = alpha_importance
+        if len(self.z_bounds) != len(self.steps_firstpass) + 1:
+            raise ValueError('len(z_bounds) must be len(steps) + 1')
+        self._tables = {}
+
+    # ---- host-side constant tables (ray independent; built with CPU torch so they are bit-equal
+    #      to what the reference's linspace / pow produce) -------------------------------------
+    def _coarse_table(self, device):
+        key = ('coarse', str(device))
+        if key not in self._tables:
+            parts = []
+            for i, s in enumerate(self.steps_firstpass):
+                lo, hi = m.log10(self.z_bounds[i]), m.log10(self.z_bounds[i + 1])
+                parts.append(torch.linspace(lo, hi - (hi - lo) / s, s))
+            zlog = torch.cat(parts)
+            self._tables[key] = (zlog.to(device), torch.pow(10, zlog).to(device))
+        return self._tables[key]
+
+    def _lin_table(self, n_importance, device):
+        key = ('lin', n_importance, str(device))
+        if key not in self._tables:
+            self._tables[key] = torch.linspace(0, 1 - 1 / n_importance, n_importance).to(device)
+        return self._tables[key]
+
+    def _steps_array(self, steps):
+        return (C.c_int32 * len(steps))(*[int(s) for s in steps])
+
+    ## Rendering Pipeline
+
+    def get_rays(self, h, w, K, E):
+        """renderer.py:38-48."""
+        hh, ww, KK, EE = i64(h).reshape(-1), i64(w).reshape(-1), f32(K).reshape(-1, 3, 3), f32(E).reshape(-1, 4, 4)
+        N = hh.shape[0]
+        rays_o = torch.empty(N, 3, device=KK.device)
+        rays_d = torch.empty(N, 3, device=KK.device)
+        check(lib().nerf_raygen(ptr(hh), ptr(ww), ptr(KK), ptr(EE), N, ptr(rays_o), ptr(rays_d), stream()), 'nerf_raygen')
+        return rays_o, rays_d
+
+    def _z_arg(self, z_vals):
+        """(tensor to keep alive, row stride) for a [N,S] depth tensor that may be a stride-0 expand."""
+        if z_vals.dim() == 2 and z_vals.stride(0) == 0 and z_vals.stride(1) == 1:
+            return z_vals[0].contiguous(), 0
+        zc = f32(z_vals)
+        return zc, zc.shape[-1]
+
+    def get_sample_points(self, rays_o, rays_d, z_vals):
+        """renderer.py:51-61."""
+        N, S = z_vals.shape
+        ro, rd = f32(rays_o), f32(rays_d)
+        z, zs = self._z_arg(z_vals)
+        xyz = torch.empty(N, S, 3, device=ro.device)
+        dirs = torch.empty(N, 3, device=ro.device)
+        check(lib().nerf_sample_points(ptr(ro), ptr(rd), ptr(z), zs, N, S, 0.0, 1.0, ptr(xyz), None, ptr(dirs), stream()),
+              'nerf_sample_points')
+        return xyz, dirs[:, None, :].expand(-1, S, -1)
+
+    def mipnerf360_scale(self, xyzs, bound_inner, bound_outer):
+        """renderer.py:64-68."""
+        x = f32(xyzs)
+        out = torch.empty_like(x)
+        check(lib().nerf_contract(ptr(x), x.numel() // 3, bound_inner, bound_outer, ptr(out), stream()), 'nerf_contract')
+        return out
+
+    def render_rays_log(self, sigmas, rgbs, z_vals, z_vals_log):
+        """renderer.py:71-85."""
+        zero_bg = torch.zeros(3, device=sigmas.device)
+        rgb, invdepth, weights, _ = _CompositeFn.apply(sigmas, rgbs, z_vals, z_vals_log, zero_bg, 0.0, 1.0)
+        return rgb, invdepth, weights
+
+    @torch.no_grad()
+    def sample_pdf(self, z_vals, weights, N_importance, noise=None, generator=None, return_inds=False):
+        """renderer.py:87-118.  ``noise`` [N, N_importance] in [0,1) replaces torch.rand of :102."""
+        N, S = weights.shape
+        pdf = f32(weights)
+        z, zs = self._z_arg(z_vals)
+        if noise is None:
+            noise = torch.rand([N, N_importance], device=pdf.device, generator=generator)
+        noise = f32(noise)
+        fine = torch.empty(N, N_importance, device=pdf.device)
+        inds = torch.empty(N, N_importance, device=pdf.device, dtype=torch.int64) if return_inds else None
+        check(lib().nerf_sample_pdf(ptr(z), zs, ptr(pdf), ptr(noise), ptr(self._lin_table(N_importance, pdf.device)), N, S,
+                                    N_importance, ptr(fine), None, ptr(inds), stream()), 'nerf_sample_pdf')
+        if return_inds:
+            return fine, inds
+        return fine
+
+    ## Calculate density distribiution along ray using forward only first pass to inform second pass
+    @torch.no_grad()
+    def get_uniform_z_vals(self, rays_o, rays_d, n_samples):
+        """renderer.py:122-129 (``n_samples`` is ignored there too)."""
+        zlog, z = self._coarse_table(rays_o.device)
+        return zlog.expand(rays_o.shape[0], -1), z.expand(rays_o.shape[0], -1)
+
+    @torch.no_grad()
+    def coarse_weights(self, sigmas, z_vals_log):
+        """renderer.py:154-160 (inline in the reference's efficient_sampling)."""
+        sig = f32(sigmas)
+        N, S = sig.shape
+        z, zs = self._z_arg(z_vals_log)
+        w = torch.empty_like(sig)
+        check(lib().nerf_coarse_weights(ptr(sig), ptr(z), zs, N, S, ptr(w), stream()), 'nerf_coarse_weights')
+        return w
+
+    @torch.no_grad()
+    def reweight_the_weights(self, weights, alpha, steps):
+        """renderer.py:132-142."""
+        w = f32(weights)
+        N, S = w.shape
+        pdf = torch.empty_like(w)
+        check(lib().nerf_reweight(ptr(w), N, S, alpha, self._steps_array(steps), len(steps), ptr(pdf), stream()),
+              'nerf_reweight')
+        return pdf
+
+    @torch.no_grad()
+    def efficient_sampling(self, rays_o, rays_d, n_samples, alpha_const, noise=None, generator=None):
+        """renderer.py:145-167."""
+        ro, rd = f32(rays_o), f32(rays_d)
+        N = ro.shape[0]
+        zlog_c, z_c = self._coarse_table(ro.device)
+        Sc = zlog_c.shape[0]
+        if isinstance(self.model, NeRFNetwork):
+            src = make_point_src(self.outer_bound, rays_o=ro, rays_d=rd, z=z_c, z_stride=0, n_samples=Sc, n_points=N * Sc,
+                                 inner_bound=self.inner_bound)
+            sigmas, _ = self.model.density_src(src)
+            sigmas = sigmas.view(N, Sc)
+        else:
+            z_vals_log, z_vals = self.get_uniform_z_vals(ro, rd, self.steps_firstpass)
+            xyzs, _ = self.get_sample_points(ro, rd, z_vals)
+            s_xyzs = self.mipnerf360_scale(xyzs, self.inner_bound, self.outer_bound)
+            sigmas, _ = self.model.density(s_xyzs, self.outer_bound)
+            sigmas = f32(sigmas)
+        if noise is None:
+            noise = torch.rand([N, n_samples], device=ro.device, generator=generator)
+        noise = f32(noise)
+        zlog_f = torch.empty(N, n_samples, device=ro.device)
+        z_f = torch.empty(N, n_samples, device=ro.device)
+        check(lib().nerf_coarse_to_fine(ptr(sigmas), ptr(zlog_c), 0, ptr(noise), ptr(self._lin_table(n_samples, ro.device)),
+                                        N, Sc, n_samples, alpha_const, self._steps_array(self.steps_firstpass),
+                                        len(self.steps_firstpass), ptr(zlog_f), ptr(z_f), stream()), 'nerf_coarse_to_fine')
+        return zlog_f, z_f
+
+    def render(self, n, h, w, K, E, bg_color, noise=None, generator=None):
+        """renderer.py:170-194."""
+        rays_o, rays_d = self.get_rays(h, w, K, E)
+        z_vals_log, z_vals = self.efficient_sampling(rays_o, rays_d, self.steps_importance, self.alpha_importance,
+                                                     noise=noise, generator=generator)
+        N, Sf = z_vals.shape
+        if isinstance(self.model, NeRFNetwork):
+            nn_ = i64(n).reshape(-1)
+            sigmas, rgbs, xh, xyzs = self.model._field(
+                dict(outer_bound=self.outer_bound, rays_o=rays_o, rays_d=rays_d, z=z_vals, z_stride=Sf, n_samples=Sf,
+                     n_points=N * Sf, n=nn_, inner_bound=self.inner_bound), want_xyz=True)
+            sigmas, rgbs, xyzs = sigmas.view(N, Sf), rgbs.view(N, Sf, 3), xyzs.view(N, Sf, 3)
+            x_hashtable = xh.view(N, Sf, -1)
+        else:
+            xyzs, dirs = self.get_sample_points(rays_o, rays_d, z_vals)
+            s_xyzs = self.mipnerf360_scale(xyzs, self.inner_bound, self.outer_bound)
+            n_expand = n[:, None].expand(-1, Sf)
+            sigmas, rgbs, aux_outputs_net = self.model(s_xyzs, dirs, n_expand, self.outer_bound)
+            x_hashtable = aux_outputs_net['x_hashtable']
+        lo = m.log10(self.z_bounds[0])
+        rng = m.log10(self.z_bounds[-1]) - lo
+        image, invdepth, weights, z_vals_log_s = _CompositeFn.apply(sigmas, rgbs, z_vals, z_vals_log, bg_color, lo, rng)
+
+        # auxilary outputs that may be useful for inference of analysis, but not used in training
+        aux_outputs = {}
+        aux_outputs['invdepth'] = invdepth.detach()
+        aux_outputs['z_vals'] = z_vals.detach()
+        aux_outputs['z_vals_log'] = z_vals_log.detach()
+        aux_outputs['sigmas'] = sigmas.detach()
+        aux_outputs['rgbs'] = rgbs.detach()
+        aux_outputs['xyzs'] = xyzs.detach()
+        aux_outputs['x_hashtable'] = x_hashtable
+        return image, weights, z_vals_log_s, aux_outputs

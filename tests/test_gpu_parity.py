@@ -1,0 +1,288 @@
+"""GPU parity tests: the HIP path (through the C ABI of libnerf_hip.so) against
+ (a) the golden vectors captured from the reference renderer and
+ (b) the CPU oracle (oracle/ref_cpu.py) on the same seeded inputs.
+Bars (BASELINE.json north_star): resampled indices bit-exact; composited RGB / depth / weights
+within 1e-4 (fp32)."""
+import math
+
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+CASES = ['a0', 'a1', 'b0', 'b1']
+
+
+def _cuda(d):
+    return {k: v.cuda() for k, v in d.items()}
+
+
+@pytest.fixture(scope='module')
+def R_for():
+    from nerf_amd.renderer import NerfRenderer
+    from oracle.ref_cpu import AnalyticField
+
+    def make(meta, model=None):
+        return NerfRenderer(model if model is not None else AnalyticField(), meta['inner'], meta['outer'],
+                            meta['z_bounds'], meta['steps'], meta['Sf'], meta['alpha'])
+    return make
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_stages_vs_golden(case, golden_meta, R_for):
+    meta, g = golden_meta[case], _cuda(load_golden(case))
+    R = R_for(meta)
+    N = meta['N']
+    rays_o, rays_d = R.get_rays(g['h'], g['w'], g['K'], g['E'])
+    assert torch.equal(rays_o, g['rays_o'])
+    torch.testing.assert_close(rays_d, g['rays_d'], rtol=2e-6, atol=2e-6)
+    zlog_c, z_c = R.get_uniform_z_vals(rays_o, rays_d, meta['steps'])
+    assert torch.equal(zlog_c[0], g['z_vals_log_coarse']) and torch.equal(z_c[0], g['z_vals_coarse'])
+    # sample points / contraction on the golden rays
+    xyz, dirs = R.get_sample_points(g['rays_o'], g['rays_d'], z_c)
+    torch.testing.assert_close(dirs[:, 0], g['dirs'], rtol=1e-6, atol=1e-7)
+    if 'xyzs_coarse' in g:
+        torch.testing.assert_close(xyz, g['xyzs_coarse'], rtol=1e-6, atol=1e-6)
+        s = R.mipnerf360_scale(g['xyzs_coarse'], meta['inner'], meta['outer'])
+        torch.testing.assert_close(s, g['s_xyzs_coarse'], rtol=1e-6, atol=1e-6)
+    # coarse weights, re-weighting, resampling on golden inputs
+    w_c = R.coarse_weights(g['sigmas_coarse'], zlog_c)
+    torch.testing.assert_close(w_c, g['weights_coarse'], rtol=1e-5, atol=1e-7)
+    w_re = R.reweight_the_weights(g['weights_coarse'], meta['alpha'], meta['steps'])
+    torch.testing.assert_close(w_re, g['weights_re'], rtol=1e-6, atol=1e-9)
+    fine, inds = R.sample_pdf(zlog_c, g['weights_re'], meta['Sf'], noise=g['noise'], return_inds=True)
+    assert torch.equal(inds, g['inds'])                                   # bit-exact indices (boundary P1)
+    assert torch.equal(fine, g['z_vals_log_fine_from_pdf'])
+    # compositing forward on the golden field outputs
+    image, weights, invdepth = None, None, None
+    rgb, invdepth, weights = R.render_rays_log(g['aux_sigmas'], g['aux_rgbs'], g['aux_z_vals'], g['aux_z_vals_log'])
+    torch.testing.assert_close(weights, g['weights'], rtol=0, atol=1e-6)
+    torch.testing.assert_close(invdepth, g['aux_invdepth'], rtol=0, atol=1e-6)
+    image = rgb + (1 - weights.sum(-1))[:, None] * g['bg']
+    torch.testing.assert_close(image, g['image'], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_composite_losses_backward_vs_golden(case, golden_meta, R_for):
+    from nerf_amd import helpers
+    from nerf_amd.renderer import _CompositeFn
+    meta, g = golden_meta[case], _cuda(load_golden(case))
+    sig = g['aux_sigmas'].clone().requires_grad_(True)
+    rgb = g['aux_rgbs'].clone().requires_grad_(True)
+    lo = math.log10(meta['z_bounds'][0])
+    rng = math.log10(meta['z_bounds'][-1]) - lo
+    image, invdepth, weights, zlog_s = _CompositeFn.apply(sig, rgb, g['aux_z_vals'], g['aux_z_vals_log'], g['bg'], lo, rng)
+    torch.testing.assert_close(image, g['image'], rtol=0, atol=1e-6)
+    torch.testing.assert_close(zlog_s, g['z_vals_log_s'], rtol=0, atol=1e-6)
+    loss, parts = helpers.fused_train_loss(image, g['rgb_gt'], weights, zlog_s, float(g['lam_dist']), float(g['lam_depth']))
+    loss.backward()
+    torch.testing.assert_close(parts[0], g['loss_rgb'], rtol=1e-5, atol=1e-9)
+    torch.testing.assert_close(parts[1], g['loss_dist'], rtol=1e-5, atol=1e-9)
+    torch.testing.assert_close(parts[2], g['loss_depth'], rtol=1e-5, atol=1e-9)
+    torch.testing.assert_close(loss.detach(), g['loss'], rtol=1e-5, atol=1e-9)
+    scale = float(g['grad_sigmas'].abs().max())
+    torch.testing.assert_close(sig.grad, g['grad_sigmas'], rtol=1e-4, atol=1e-5 * scale)
+    torch.testing.assert_close(rgb.grad, g['grad_rgbs'], rtol=1e-4, atol=1e-5 * float(g['grad_rgbs'].abs().max()))
+    assert abs(helpers.psnr(image.detach(), g['rgb_gt']) - float(g['psnr'])) < 1e-4
+    # individual reference-named losses, and the unsorted O(S^2) form of criterion_dist
+    torch.testing.assert_close(helpers.criterion_rgb(g['image'], g['rgb_gt']), g['loss_rgb'], rtol=1e-5, atol=1e-9)
+    torch.testing.assert_close(helpers.criterion_dist(g['weights'], g['z_vals_log_s']), g['loss_dist'], rtol=1e-5, atol=1e-9)
+    torch.testing.assert_close(helpers.criterion_dist(g['weights'], g['z_vals_log_s'], assume_sorted=False), g['loss_dist'],
+                               rtol=1e-5, atol=1e-9)
+    from nerf_amd.inference import Inferencer
+    inf = Inferencer(None, 4096, 0, 0, 0.1, 0.05, 0.4, [1, 2, 3, 4], 20)
+    for t in (0.3, 0.5, 0.7):
+        assert torch.equal(inf.calculate_cumlative_weights_thresh(g['weights'], t), g['cum_thresh_%d' % int(t * 10)])
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_render_stub_field_vs_golden(case, golden_meta, R_for):
+    """Whole render() with the analytic stub field: every renderer stage in HIP, field in torch."""
+    meta, g = golden_meta[case], _cuda(load_golden(case))
+    R = R_for(meta)
+    image, weights, zlog_s, aux = R.render(g['n'], g['h'], g['w'], g['K'], g['E'], g['bg'], noise=g['noise'])
+    torch.testing.assert_close(aux['z_vals_log'], g['aux_z_vals_log'], rtol=0, atol=2e-5)
+    torch.testing.assert_close(image, g['image'], rtol=0, atol=1e-4)
+    torch.testing.assert_close(weights, g['weights'], rtol=0, atol=1e-4)
+    torch.testing.assert_close(aux['invdepth'], g['aux_invdepth'], rtol=0, atol=1e-4)
+    torch.testing.assert_close(zlog_s, g['z_vals_log_s'], rtol=0, atol=2e-5)
+
+
+def test_edges(R_for):
+    g = _cuda(load_golden('edges'))
+    meta = dict(inner=2, outer=2.5, z_bounds=[1.6, 4.8], steps=[64], Sf=128, alpha=0.2)
+    R = R_for(meta)
+    zlog_c, _ = R.get_uniform_z_vals(torch.zeros(5, 3, device='cuda'), None, None)
+    w = R.coarse_weights(g['sigmas'], zlog_c)
+    torch.testing.assert_close(w, g['weights'], rtol=1e-5, atol=1e-7)
+    assert float(w[4].sum()) == 0.0
+    fine, inds = R.sample_pdf(zlog_c, g['weights_re'], 128, noise=g['noise'], return_inds=True)
+    assert torch.equal(inds, g['inds']) and torch.equal(fine, g['z_vals_log_fine'])
+    fine_t, inds_t = R.sample_pdf(g['tie_zlog'], g['tie_pdf'], 8, noise=g['tie_noise'], return_inds=True)
+    assert torch.equal(inds_t, g['tie_inds'])
+    assert torch.equal(torch.nan_to_num(fine_t, nan=-7.0), torch.nan_to_num(g['tie_fine'], nan=-7.0))
+    torch.testing.assert_close(R.mipnerf360_scale(g['contract_pts'], 2, 2.5), g['contract_2_25'], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(R.mipnerf360_scale(g['contract_pts'], 1, 2), g['contract_1_2'], rtol=1e-6, atol=1e-6)
+    # ragged / tail sizes: 1, 3 and 5 rays (a partial 4-ray block), empty input
+    for n in (1, 3, 5):
+        f2, i2 = R.sample_pdf(zlog_c[:n], g['weights_re'][:n], 128, noise=g['noise'][:n], return_inds=True)
+        assert torch.equal(i2, g['inds'][:n]) and torch.equal(f2, g['z_vals_log_fine'][:n])
+    e = R.sample_pdf(zlog_c[:0], g['weights_re'][:0], 128, noise=g['noise'][:0])
+    assert e.shape == (0, 128)
+
+
+NET_CFGS = {
+    'small': dict(encoding_n_levels=8, encoding_log2_hashmap_size=15),
+    'odd': dict(encoding_n_levels=5, encoding_log2_hashmap_size=14),
+    'base19': dict(encoding_n_levels=20, encoding_log2_hashmap_size=19),
+}
+
+
+def _make_pair(cfg, n_img=7, seed=3):
+    """NeRFNetwork on the GPU and an OracleNetwork on the CPU holding identical parameters."""
+    from nerf_amd.nets import NeRFNetwork
+    from oracle.ref_cpu import OracleNetwork
+    kw = dict(encoding_precision='float32', encoding_n_features_per_level=2, geo_feat_dim=15, sigma_hidden_dim=64,
+              sigma_num_layers=2, encoding_dir_precision='float32', encoding_dir_encoding='SphericalHarmonics',
+              encoding_dir_degree=4, latent_embedding_dim=48, color_hidden_dim=64, color_num_layers=3)
+    kw.update(cfg)
+    ora = OracleNetwork(n_img, seed=seed, **kw)
+    with torch.no_grad():
+        ora.encoder_params.mul_(1e3)      # lift the table out of its 1e-4 init so features matter
+        ora.latent_emb.copy_(torch.randn(n_img, 48, generator=torch.Generator().manual_seed(seed)) * 0.3)
+    net = NeRFNetwork(n_img, **kw)
+    with torch.no_grad():
+        assert net.encoder.params.numel() == ora.encoder_params.numel()
+        net.encoder.params.copy_(ora.encoder_params)
+        net.sigma_net.params.copy_(ora.sigma_params)
+        net.color_net.params.copy_(ora.color_params)
+        net.latent_emb.copy_(ora.latent_emb)
+    return net, ora
+
+
+@pytest.mark.parametrize('name', list(NET_CFGS))
+def test_field_forward_backward_vs_oracle(name):
+    net, ora = _make_pair(NET_CFGS[name])
+    g = torch.Generator().manual_seed(11)
+    M = 1000 if name != 'base19' else 517     # ragged: not a multiple of 32 / 128
+    x = (torch.rand(M, 3, generator=g) * 2 - 1) * 2.4
+    d = torch.randn(M, 3, generator=g)
+    d = d / d.norm(dim=-1, keepdim=True)
+    n = torch.randint(0, 7, (M,), generator=g)
+    ob = 2.5
+    # stand-alone encoding
+    x01 = (x + ob) / (2 * ob)
+    enc_o = ora.encode(x01)
+    enc_g = net.encoder(x01.cuda())
+    torch.testing.assert_close(enc_g.cpu(), enc_o, rtol=1e-5, atol=1e-7)
+    # density + full field
+    sig_o, rgb_o, aux_o = ora(x, d, n, ob)
+    sig_d, aux_d = net.density(x.cuda(), ob)
+    sig_g, rgb_g, aux_g = net(x.cuda(), d.cuda(), n.cuda(), ob)
+    scale = float(sig_o.abs().max()) + 1e-6
+    torch.testing.assert_close(sig_g.cpu(), sig_o, rtol=1e-4, atol=1e-5 * scale)
+    torch.testing.assert_close(sig_d.cpu(), sig_o, rtol=1e-4, atol=1e-5 * scale)
+    torch.testing.assert_close(rgb_g.cpu(), rgb_o, rtol=0, atol=1e-5)
+    torch.testing.assert_close(aux_g['x_hashtable'].cpu(), aux_o['x_hashtable'], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(aux_d['x_hashtable'].cpu(), aux_o['x_hashtable'], rtol=1e-5, atol=1e-7)
+    # backward: random upstream gradients
+    gs = torch.randn(M, generator=g)
+    gc = torch.randn(M, 3, generator=g)
+    (sig_o * gs).sum().add((rgb_o * gc).sum()).backward()
+    (sig_g * gs.cuda()).sum().add((rgb_g * gc.cuda()).sum()).backward()
+    for a, b, what in ((net.sigma_net.params.grad, ora.sigma_params.grad, 'sigma_net'),
+                       (net.color_net.params.grad, ora.color_params.grad, 'color_net'),
+                       (net.latent_emb.grad, ora.latent_emb.grad, 'latent'),
+                       (net.encoder.params.grad, ora.encoder_params.grad, 'table')):
+        s = float(b.abs().max()) + 1e-12
+        torch.testing.assert_close(a.cpu(), b, rtol=1e-3, atol=2e-5 * s, msg=lambda m, w=what: w + ': ' + m)
+
+
+def _batch(loader_seed, N, n_img=7):
+    import sys
+    sys.path.insert(0, 'tests/golden')
+    from nerf_amd.loaders.procedural import sphere_cameras
+    K_all, E_all = sphere_cameras(n_img, loader_seed)
+    g = torch.Generator().manual_seed(50 + loader_seed)
+    n = torch.randint(0, n_img, (N,), generator=g)
+    h = torch.randint(0, 800, (N,), generator=g)
+    w = torch.randint(0, 800, (N,), generator=g)
+    return n, h, w, K_all[n], E_all[n], torch.rand(3, generator=g), torch.rand(N, 128, generator=g), torch.rand(N, 3, generator=g)
+
+
+@pytest.mark.parametrize('steps,zb', [([64], [1.6, 4.8]), ([256, 128, 64, 32], [0.1, 1, 10, 100, 1000])])
+def test_render_fused_vs_oracle(steps, zb):
+    """Full render() with the HIP field network vs the CPU oracle on identical rays and weights."""
+    from nerf_amd.renderer import NerfRenderer
+    from oracle.ref_cpu import OracleRenderer
+    net, ora = _make_pair(NET_CFGS['small'])
+    n, h, w, K, E, bg, noise, gt = _batch(1, 130)
+    Ro = OracleRenderer(ora, 2, 2.5, zb, steps, 128, 0.2)
+    Rg = NerfRenderer(net, 2, 2.5, zb, steps, 128, 0.2)
+    with torch.no_grad():
+        img_o, w_o, zs_o, aux_o = Ro.render(n, h, w, K, E, bg, noise=noise)
+    img_g, w_g, zs_g, aux_g = Rg.render(n.cuda(), h.cuda(), w.cuda(), K.cuda(), E.cuda(), bg.cuda(), noise=noise.cuda())
+    torch.testing.assert_close(aux_g['z_vals_log'].cpu(), aux_o['z_vals_log'], rtol=0, atol=5e-5)
+    torch.testing.assert_close(img_g.detach().cpu(), img_o, rtol=0, atol=1e-4)
+    torch.testing.assert_close(w_g.detach().cpu(), w_o, rtol=0, atol=1e-4)
+    torch.testing.assert_close(aux_g['invdepth'].cpu(), aux_o['invdepth'], rtol=0, atol=1e-4)
+    torch.testing.assert_close(aux_g['xyzs'].cpu(), aux_o['xyzs'], rtol=1e-4, atol=1e-3)
+
+
+def test_adam_vs_torch():
+    from nerf_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(5)
+    p0 = torch.randn(10007, generator=g)
+    pc = torch.nn.Parameter(p0.clone())
+    pg = torch.nn.Parameter(p0.clone().cuda())
+    oc = torch.optim.Adam([{'params': [pc], 'lr': 2e-2, 'weight_decay': 1e-6}], betas=(0.9, 0.99), eps=1e-15)
+    og = FusedAdam([{'params': [pg], 'lr': 2e-2, 'weight_decay': 1e-6}], betas=(0.9, 0.99), eps=1e-15)
+    for it in range(5):
+        gr = torch.randn(10007, generator=g) * (0.1 if it != 2 else 0.0)   # step 2: all-zero gradient
+        pc.grad = gr.clone()
+        pg.grad = gr.clone().cuda()
+        oc.step()
+        og.step()
+        assert float(pg.grad.abs().max()) == 0.0          # cleared in the same pass
+        torch.testing.assert_close(pg.detach().cpu(), pc.detach(), rtol=1e-5, atol=1e-6)
+
+
+def test_train_steps_vs_oracle():
+    """A short training trace (loss per step) of the HIP path against the CPU oracle:
+    same rays, same noise, same init, Adam groups of train.py:84-88."""
+    from nerf_amd.optim import FusedAdam
+    from nerf_amd.renderer import NerfRenderer
+    from nerf_amd import helpers
+    from oracle import ref_cpu
+    net, ora = _make_pair(NET_CFGS['small'])
+    with torch.no_grad():
+        ora.latent_emb.zero_()
+        net.latent_emb.zero_()
+    Ro = ref_cpu.OracleRenderer(ora, 2, 2.5, [1.6, 4.8], [64], 128, 0.2)
+    Rg = NerfRenderer(net, 2, 2.5, [1.6, 4.8], [64], 128, 0.2)
+    oo = ref_cpu.make_optimizer(ora)
+    og = FusedAdam([{'params': list(net.encoder.parameters()), 'lr': 2e-2},
+                    {'params': [net.latent_emb], 'lr': 2e-2},
+                    {'params': list(net.sigma_net.parameters()) + list(net.color_net.parameters()), 'weight_decay': 1e-6, 'lr': 1e-3}],
+                   betas=(0.9, 0.99), eps=1e-15).attach(net)
+    lo, lg = [], []
+    for it in range(4):
+        n, h, w, K, E, bg, noise, gt = _batch(10 + it, 96)
+        oo.zero_grad()
+        img, wts, zs, _ = Ro.render(n, h, w, K, E, bg, noise=noise)
+        loss, _ = ref_cpu.train_loss(img, gt, wts, zs, it, 100, 1e-5, 1e-2, 1e-1, 1e-1)
+        loss.backward()
+        oo.step()
+        lo.append(float(loss))
+        og.zero_grad()
+        img, wts, zs, _ = Rg.render(n.cuda(), h.cuda(), w.cuda(), K.cuda(), E.cuda(), bg.cuda(), noise=noise.cuda())
+        lam_d = ref_cpu.dist_scalar(it, 100, 1e-5, 1e-2)
+        loss_g, _ = helpers.fused_train_loss(img, gt.cuda(), wts, zs, lam_d, 1e-1)
+        loss_g.backward()
+        og.step()
+        lg.append(float(loss_g))
+    for a, b in zip(lg, lo):
+        assert abs(a - b) <= 2e-4 * max(1.0, abs(b)), (lg, lo)
+    torch.testing.assert_close(net.sigma_net.params.detach().cpu(), ora.sigma_params.detach(), rtol=0, atol=2e-3)
