@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""Benchmark of the render-and-train hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+Metric (BASELINE.json): rays/sec (train step + render) at 64 coarse + 128 fine samples/ray.
+A "step" is one training step on a batch of `--rays` rays PER GPU (weak scaling): device-side
+batch sampling, render (ray generation, coarse density pass, resampling, fine field pass,
+compositing), fused losses, backward (compositing, field network, hash-table scatter), gradient
+all-reduce over RCCL when N > 1, and the dense fused Adam step over every parameter (the
+reference's torch.optim.Adam semantics, train.py:84-88).  Network and renderer are the metric
+config: config_base network (20 levels x 2 features, 2^24 table, SH4, latent 48, 64-wide MLPs),
+steps [64], z_bounds [1.6, 4.8], 128 importance samples; synthetic procedural scene
+(100 poses, 800x800), random-init weights.  Inputs are resident in HBM when the timed region starts.
+
+The JSON line also carries
+  * "render": full 800x800 image inference (BASELINE configs[1]) in rays/s, measured after the
+    training steps with the same weights;
+  * "roofline" for the kernel that takes the largest share of the step, from live per-launch
+    device timings (HIP events on the launch stream);
+  * "kernels": the per-entry-point breakdown the roofline figure was picked from;
+  * "cpu_baseline": the CPU oracle (oracle/ref_cpu.py, a port: the reference network cannot run on
+    a CPU) timed on this box's host cores on a bounded sample of the same workload (rank 0, N=1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # f32-input MFMA (v_mfma_f32_32x32x2_f32), dense
+
+NET = dict(encoding_precision='float32', encoding_n_levels=20, encoding_n_features_per_level=2,
+           encoding_log2_hashmap_size=24, geo_feat_dim=15, sigma_hidden_dim=64, sigma_num_layers=2,
+           encoding_dir_precision='float32', encoding_dir_encoding='SphericalHarmonics', encoding_dir_degree=4,
+           latent_embedding_dim=48, color_hidden_dim=64, color_num_layers=3)
+STEPS, Z_BOUNDS, SF, ALPHA, INNER, OUTER = [64], [1.6, 4.8], 128, 0.2, 2, 2.5
+N_IMAGES, H, W = 100, 800, 800
+
+
+def algorithmic_bytes(name, n_rays, n_params, Sc=64, Sf=SF, L=20, F=2):
+    """Algorithmic HBM bytes of ONE launch (SURVEY.md section 8d per-unit figures x units per launch)."""
+    gather = L * 8 * F * 4                       # 1280 B / point
+    return {
+        'nerf_density_fwd': n_rays * Sc * (gather + 4),
+        'nerf_field_fwd': n_rays * Sf * (gather + L * F * 4 + 4 + 12 + 12),
+        'nerf_field_bwd': n_rays * Sf * (2 * gather + L * F * 4 + 4 + 12),
+        'nerf_adam_step': None,                  # per-tensor launches: 32 B / parameter, summed below
+        'nerf_coarse_to_fine': n_rays * (4 * Sc + 12 * Sf),
+        'nerf_composite_fwd': n_rays * (Sf * 32 + 16),
+        'nerf_composite_bwd': n_rays * (Sf * 44 + 12),
+        'nerf_losses': n_rays * (Sf * 12 + 36),
+        'nerf_raygen': n_rays * (16 + 36 + 64 + 24),
+    }.get(name)
+
+
+def algorithmic_flops(name, n_rays, Sc=64, Sf=SF):
+    return {'nerf_density_fwd': n_rays * Sc * 7168, 'nerf_field_fwd': n_rays * Sf * 25856,
+            'nerf_field_bwd': n_rays * Sf * 3 * 25856}.get(name)
+
+
+def build_gpu(device, rank, n_rays):
+    from nerf_amd.loaders.procedural import ProceduralSceneLoader
+    from nerf_amd.nets import NeRFNetwork
+    from nerf_amd.optim import FusedAdam
+    from nerf_amd.renderer import NerfRenderer
+    model = NeRFNetwork(N_IMAGES, device=device, seed=0, **NET)
+    renderer = NerfRenderer(model, INNER, OUTER, Z_BOUNDS, STEPS, SF, ALPHA)
+    loader = ProceduralSceneLoader(N_IMAGES, H, W, seed=0, device=device, batch_seed=1000 + rank)
+    opt = FusedAdam([
+        {'name': 'encoding', 'params': list(model.encoder.parameters()), 'lr': 2e-2},
+        {'name': 'latent_emb', 'params': [model.latent_emb], 'lr': 2e-2},
+        {'name': 'net', 'params': list(model.sigma_net.parameters()) + list(model.color_net.parameters()),
+         'weight_decay': 1e-6, 'lr': 1e-3}], betas=(0.9, 0.99), eps=1e-15).attach(model)
+    return model, renderer, loader, opt
+
+
+def train_step(model, renderer, loader, opt, n_rays, it, world):
+    from nerf_amd import helpers, parallel
+    opt.zero_grad()
+    n, h, w, K, E, rgb_gt, color_bg, _ = loader.get_random_batch(n_rays)
+    rgb, weights, zs, _ = renderer.render(n, h, w, K, E, color_bg)
+    lam_dist = 10 ** (it / 10000 * 3 - 5)            # trainer.py:160 with lambda 1e-5 -> 1e-2 over 10k iters
+    loss, _ = helpers.fused_train_loss(rgb, rgb_gt, weights, zs, lam_dist, 1e-1)
+    loss.backward()
+    if world > 1:
+        parallel.all_reduce_grads([p for g in opt.param_groups for p in g['params']])
+        opt.grad_scale = 1.0 / world
+    opt.step()
+    return loss
+
+
+def cpu_baseline(n_rays=1024, steps=2, threads=16):
+    """The CPU oracle on a bounded sample: `steps` train steps of `n_rays` rays, config_base network."""
+    from oracle import ref_cpu
+    from nerf_amd.loaders.procedural import sphere_cameras
+    torch.set_num_threads(threads)
+    ora = ref_cpu.OracleNetwork(N_IMAGES, seed=0, **NET)
+    R = ref_cpu.OracleRenderer(ora, INNER, OUTER, Z_BOUNDS, STEPS, SF, ALPHA)
+    opt = ref_cpu.make_optimizer(ora)
+    K_all, E_all = sphere_cameras(N_IMAGES, 0)
+    g = torch.Generator().manual_seed(0)
+    times = []
+    for it in range(steps + 1):
+        n = torch.randint(0, N_IMAGES, (n_rays,), generator=g)
+        h = torch.randint(0, H, (n_rays,), generator=g)
+        w = torch.randint(0, W, (n_rays,), generator=g)
+        bg, gt = torch.rand(3, generator=g), torch.rand(n_rays, 3, generator=g)
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        img, wts, zs, _ = R.render(n, h, w, K_all[n], E_all[n], bg)
+        loss, _ = ref_cpu.train_loss(img, gt, wts, zs, it, 10000, 1e-5, 1e-2, 1e-1, 1e-1)
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    t = sorted(times[1:])[len(times[1:]) // 2]
+    return {'value': n_rays / t, 'unit': 'rays/s', 'cores': threads, 'kind': 'port',
+            'sample': '%d train steps of %d rays (1 warm-up), oracle/ref_cpu.py fp32 torch CPU, same network/renderer config'
+                      % (steps, n_rays), 'seconds_per_step': t}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--rays', type=int, default=4096, help='rays per GPU per step')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-render', action='store_true')
+    ap.add_argument('--profile-steps', type=int, default=5)
+    args = ap.parse_args()
+
+    from nerf_amd import _lib, parallel
+    rank, world, local = parallel.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    device = torch.device('cuda', local if world > 1 else 0)
+    torch.cuda.set_device(device)
+    import torch.distributed as dist
+
+    model, renderer, loader, opt = build_gpu(device, rank, args.rays)
+    n_params = sum(p.numel() for g in opt.param_groups for p in g['params'])
+
+    for it in range(args.warmup):
+        train_step(model, renderer, loader, opt, args.rays, it, world)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(args.steps):
+        train_step(model, renderer, loader, opt, args.rays, args.warmup + it, world)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * args.rays * args.steps / elapsed
+
+    # ---- per-kernel device times (live, HIP events on the launch stream) ----
+    _lib.kernel_timing(True)
+    for it in range(args.profile_steps):
+        train_step(model, renderer, loader, opt, args.rays, it, world)
+    prof = _lib.kernel_timing(False)
+    kernels = []
+    for name, (launches, total_ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
+        per_step_ms = total_ms / args.profile_steps
+        if name == 'nerf_adam_step':
+            bytes_step = 32 * n_params
+        else:
+            b = algorithmic_bytes(name, args.rays, n_params)
+            bytes_step = b * (launches / args.profile_steps) if b else None
+        k = {'name': name, 'launches_per_step': launches / args.profile_steps, 'ms_per_step': round(per_step_ms, 4)}
+        if bytes_step:
+            k['algorithmic_GBps'] = round(bytes_step / (per_step_ms * 1e-3) / 1e9, 1)
+            k['hbm_frac'] = round(k['algorithmic_GBps'] / HBM_PEAK_GBS, 4)
+        fl = algorithmic_flops(name, args.rays)
+        if fl:
+            k['algorithmic_TFLOPs'] = round(fl / (per_step_ms * 1e-3) / 1e12, 2)
+            k['mfma_f32_frac'] = round(k['algorithmic_TFLOPs'] / MFMA_F32_PEAK_TFLOPS, 4)
+        kernels.append(k)
+    dom = kernels[0]
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+    if os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get(dom['name'])
+    roofline = {'kernel': dom['name'], 'bound': 'hbm', 'achieved': dom.get('algorithmic_GBps'), 'peak': HBM_PEAK_GBS,
+                'unit': 'GB/s', 'frac': dom.get('hbm_frac'), 'traffic': traffic,
+                'avg_launch_ms': round(dom['ms_per_step'] / dom['launches_per_step'], 4)}
+
+    # ---- 800x800 inference (BASELINE configs[1]) ----
+    render = None
+    if not args.no_render:
+        from nerf_amd.inference import Inferencer
+        inf = Inferencer(renderer, 65536, 0, 0, 0.1, 0.05, 0.4, [1, 2, 3, 4], 20)
+        n, h, w, K, E, _, _, _ = loader.get_image_batch(0)
+        inf.render_image(n, h, w, K, E)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            inf.render_image(n, h, w, K, E)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / reps
+        render = {'workload': '800x800 image, 64+128 samples/ray, chunks of 65536 rays, sharded over %d GPU(s)' % world,
+                  'rays_per_s': H * W / dt, 'ms_per_image': dt * 1e3}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        del model, renderer, loader, opt
+        torch.cuda.empty_cache()
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        out = {
+            'metric': 'rays/sec (train step + render) at 64+128 samples/ray', 'value': value, 'unit': 'rays/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'train step (render + backward + dense Adam), %d rays/GPU/step, 64 coarse + 128 fine '
+                                   'samples/ray, config_base network (L20 F2 T24, SH4, latent 48, 64-wide MLPs), '
+                                   'procedural scene 100 poses 800x800' % args.rays,
+                       'rays_per_gpu': args.rays, 'global_rays': args.rays * world, 'parallelism': 'dp%d' % world},
+            'roofline': roofline, 'cpu_baseline': cpu, 'render': render, 'kernels': kernels,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

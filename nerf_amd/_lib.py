@@ -63,6 +63,41 @@ SIGNATURES = {
 }
 
 _lib = None
+_prof = None   # name -> list of (start_event, end_event) while kernel timing is on
+
+
+class _Timed(object):
+    """Wraps one entry point; when kernel timing is on, brackets the call with events recorded on
+    the stream the kernel is launched on (torch's current stream, which is what `stream()` passes)."""
+
+    def __init__(self, name, fn):
+        self.name, self.fn = name, fn
+
+    def __call__(self, *args):
+        if _prof is None:
+            return self.fn(*args)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = self.fn(*args)
+        b.record()
+        _prof.setdefault(self.name, []).append((a, b))
+        return rc
+
+
+def kernel_timing(on):
+    """Start (True) or stop (False) per-entry-point device timing.  Stopping returns
+    {name: (launches, total_ms)} after synchronising."""
+    global _prof
+    if on:
+        _prof = {}
+        return None
+    rec, _prof = _prof, None
+    torch.cuda.synchronize()
+    return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in (rec or {}).items()}
+
+
+class _Lib(object):
+    pass
 
 
 def lib():
@@ -72,11 +107,14 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError('libnerf_hip.so is missing (%s). Build it with `make -C nerf_amd/csrc`; '
                                'nerf_amd has no fallback path.' % LIB_PATH)
-        l = C.CDLL(LIB_PATH)
+        dll = C.CDLL(LIB_PATH)
+        l = _Lib()
         for name, (res, args) in SIGNATURES.items():
-            fn = getattr(l, name)
+            fn = getattr(dll, name)
             fn.restype = res
             fn.argtypes = args
+            launches = res is _I and name not in ('nerf_abi_version',)
+            setattr(l, name, _Timed(name, fn) if launches else fn)
         if l.nerf_abi_version() != 1:
             raise RuntimeError('libnerf_hip.so ABI version mismatch')
         _lib = l

@@ -36,7 +36,8 @@ extern "C" int64_t nerf_grid_cfg_init(NerfGridCfg* cfg, int n_levels, int n_feat
     const float log2_pls = (float)log2((double)per_level_scale);
     uint64_t offset = 0;
     for (int l = 0; l < n_levels; ++l) {
-        float scale = exp2f((float)l * log2_pls) * (float)base_resolution - 1.0f;
+        const float expo = (float)l * log2_pls;
+        const float scale = (float)(exp2((double)expo) * (double)base_resolution - 1.0);
         uint64_t res = (uint64_t)ceilf(scale) + 1;
         uint64_t full = res * res * res;
         uint64_t entries = ((full + 7) / 8) * 8;

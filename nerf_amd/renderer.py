@@ -102,7 +102,7 @@ class NerfRenderer(nn.Module):
 
     def _z_arg(self, z_vals):
         """(tensor to keep alive, row stride) for a [N,S] depth tensor that may be a stride-0 expand."""
-        if z_vals.dim() == 2 and z_vals.stride(0) == 0 and z_vals.stride(1) == 1:
+        if z_vals.dim() == 2 and z_vals.shape[0] > 0 and z_vals.stride(0) == 0 and z_vals.stride(1) == 1:
             return z_vals[0].contiguous(), 0
         zc = f32(z_vals)
         return zc, zc.shape[-1]
@@ -142,6 +142,8 @@ class NerfRenderer(nn.Module):
         noise = f32(noise)
         fine = torch.empty(N, N_importance, device=pdf.device)
         inds = torch.empty(N, N_importance, device=pdf.device, dtype=torch.int64) if return_inds else None
+        if N == 0:
+            return (fine, inds) if return_inds else fine
         check(lib().nerf_sample_pdf(ptr(z), zs, ptr(pdf), ptr(noise), ptr(self._lin_table(N_importance, pdf.device)), N, S,
                                     N_importance, ptr(fine), None, ptr(inds), stream()), 'nerf_sample_pdf')
         if return_inds:

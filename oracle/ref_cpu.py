@@ -54,10 +54,12 @@ def grid_levels(n_levels, log2_hashmap_size, base_resolution=16, per_level_scale
     """Per-level geometry.  base_resolution / per_level_scale are hard-coded at nets.py:46-47."""
     levels = []
     offset = 0
-    log2_pls = math.log2(per_level_scale)
+    # per_level_scale is an fp32 config value (tcnn reads it as float); log2 / exp2 are evaluated in
+    # double on fp32-rounded arguments and rounded once, so host libm differences cannot leak in
+    log2_pls = np.float32(math.log2(float(np.float32(per_level_scale))))
     for l in range(n_levels):
-        # tcnn evaluates these in fp32 (exp2f, ceilf)
-        scale = float(np.float32(np.exp2(np.float32(l * np.float32(log2_pls))) * np.float32(base_resolution) - np.float32(1.0)))
+        expo = float(np.float32(l) * log2_pls)
+        scale = float(np.float32(float(np.exp2(np.float64(expo))) * base_resolution - 1.0))
         res = int(math.ceil(scale)) + 1
         full = res ** 3
         entries = min(((full + 7) // 8) * 8, 1 << log2_hashmap_size)

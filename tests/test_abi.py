@@ -40,7 +40,7 @@ def test_host_side_config_helpers():
         for i, lv in enumerate(levels):
             assert cfg.res[i] == lv.res and cfg.entries[i] == lv.entries and cfg.offset[i] == lv.offset
             assert bool(cfg.hashed[i]) == lv.hashed
-            assert abs(cfg.scale[i] - lv.scale) <= 1e-6 * lv.scale
+            assert cfg.scale[i] == lv.scale      # bit-equal: the cell a point falls in depends on it
     net = _lib.NerfNetCfg(64, 2, 15, 3, 4, 48)
     cfg = _lib.NerfGridCfg()
     l.nerf_grid_cfg_init(ctypes.byref(cfg), 20, 2, 24, 16, 1.3819)
