@@ -50,7 +50,8 @@ def algorithmic_bytes(name, n_rays, n_params, Sc=64, Sf=SF, L=20, F=2):
     return {
         'nerf_density_fwd': n_rays * Sc * (gather + 4),
         'nerf_field_fwd': n_rays * Sf * (gather + L * F * 4 + 4 + 12 + 12),
-        'nerf_field_bwd': n_rays * Sf * (2 * gather + L * F * 4 + 4 + 12),
+        'nerf_field_bwd': n_rays * Sf * (2 * L * F * 4 + 4 + 12),
+        'nerf_hashgrid_scatter': n_rays * Sf * (2 * gather + L * F * 4),
         'nerf_adam_step': None,                  # per-tensor launches: 32 B / parameter, summed below
         'nerf_coarse_to_fine': n_rays * (4 * Sc + 12 * Sf),
         'nerf_composite_fwd': n_rays * (Sf * 32 + 16),
@@ -168,10 +169,11 @@ def main():
     value = world * args.rays * args.steps / elapsed
 
     # ---- per-kernel device times (live, HIP events on the launch stream) ----
-    _lib.kernel_timing(True)
+    if args.profile_steps > 0:
+        _lib.kernel_timing(True)
     for it in range(args.profile_steps):
         train_step(model, renderer, loader, opt, args.rays, it, world)
-    prof = _lib.kernel_timing(False)
+    prof = _lib.kernel_timing(False) if args.profile_steps > 0 else {}
     kernels = []
     for name, (launches, total_ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
         per_step_ms = total_ms / args.profile_steps
@@ -189,7 +191,7 @@ def main():
             k['algorithmic_TFLOPs'] = round(fl / (per_step_ms * 1e-3) / 1e12, 2)
             k['mfma_f32_frac'] = round(k['algorithmic_TFLOPs'] / MFMA_F32_PEAK_TFLOPS, 4)
         kernels.append(k)
-    dom = kernels[0]
+    dom = kernels[0] if kernels else {'name': None, 'ms_per_step': 0.0, 'launches_per_step': 1.0}
     traffic = None
     tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
     if os.path.exists(tpath):

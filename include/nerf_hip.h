@@ -119,11 +119,19 @@ int nerf_field_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const float* 
                    const NerfPointSrc* src, float* sigma, float* rgb, float* x_hashtable /*nullable*/,
                    float* xyz /*nullable*/, void* stream);
 /* Backward of nerf_field_fwd (what autograd + tcnn do under trainer.py:134).  Gradients are
- * ACCUMULATED into dtable / dsigma_params / dcolor_params / dlatent (caller zeroes them). */
+ * ACCUMULATED into dtable / dsigma_params / dcolor_params / dlatent (caller zeroes them).
+ * dfeat [M, L*F] receives d(loss)/d(hash-grid features) (it is also the staging buffer between the
+ * MLP-backward launch and the table-scatter launch); dtable may be NULL to skip the scatter. */
 int nerf_field_bwd(const NerfGridCfg* grid, const NerfNetCfg* net, const float* table, const float* sigma_params,
                    const float* color_params, const float* latent_emb, int64_t n_images, const NerfPointSrc* src,
                    const float* x_hashtable, const float* dsigma /*[M]*/, const float* drgb /*[M,3]*/,
-                   float* dtable, float* dsigma_params, float* dcolor_params, float* dlatent, void* stream);
+                   float* dfeat /*[M,L*F]*/, float* dtable, float* dsigma_params, float* dcolor_params,
+                   float* dlatent, void* stream);
+
+/* The table-scatter half of nerf_field_bwd on its own: dtable += scatter(dfeat) for the points of `src`
+ * (the same trilinear weights as the forward gather; what tcnn's HashGrid backward does). */
+int nerf_hashgrid_scatter(const NerfGridCfg* grid, const NerfPointSrc* src, const float* dfeat /*[M,L*F]*/,
+                          float* dtable, void* stream);
 
 /* ---- hierarchical resampling ---- */
 /* renderer.py:154-160: alpha = 1-exp(-sigma*delta), exclusive transmittance, weights. zlog has

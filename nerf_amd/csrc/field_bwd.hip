@@ -2,8 +2,8 @@
 // tiles; each of its 4 wavefronts re-runs the forward for its own 32 points from the saved
 // hash-grid features (x_hashtable), back-propagates through both MLPs with the same
 // register-resident MFMA chains as the forward (A operand = W^T read from the same LDS image),
-// scatters d(loss)/d(features) into the hash table with fp32 atomics and reduces the latent
-// gradient across the wavefront.  Weight gradients dW = dZ * H^T are summed over the 128 points
+// writes d(loss)/d(features) out for the table-scatter launch that follows and reduces the
+// latent gradient across the wavefront.  Weight gradients dW = dZ * H^T are summed over the 128 points
 // on the matrix cores too: each (dZ, H) pair is staged once through LDS as [unit][point], and
 // every wavefront owns a fixed subset of the 18 32x32 dW tiles in accumulators that persist
 // for the whole launch (one atomic flush per workgroup at the end).
@@ -17,7 +17,6 @@ namespace {
 
 constexpr int kBlockPts = 128;
 constexpr int kSP = kBlockPts + 1;  // staging pitch (odd -> conflict-free row walks)
-constexpr int kSXP = 4 * 64 + 1;      // pitch of the per-lane gradient parking area
 
 // acc += SA[a_tile rows][:] * SB[b_tile rows][:]^T over the 128 staged points
 __device__ __forceinline__ f32x16 dw_tile(f32x16 acc, const float* SA, const float* SB, int a_tile, int b_tile, int n_out,
@@ -66,14 +65,13 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
                                                            const float* __restrict__ color_w,
                                                            const float* __restrict__ latent, NerfPointSrc src,
                                                            const float* __restrict__ xh, const float* __restrict__ dsigma,
-                                                           const float* __restrict__ drgb, float* __restrict__ dtable,
+                                                           const float* __restrict__ drgb, float* __restrict__ dfeat,
                                                            float* __restrict__ dsw, float* __restrict__ dcw,
                                                            float* __restrict__ dlatent, int sb_rows) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     lds_load_net(lds, s, sigma_w, color_w, true);
     float* SA = lds + s.total;
     float* SB = SA + kHid * kSP;
-    float* SX = SB + sb_rows * kSP;  // [LH*F][256 lanes]
 
     const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -315,26 +313,14 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
                 x1 = MFMA32(live1 ? w1[kk] : 0.f, g1[t], x1);
             }
         }
-        // ------------------------- hash-table scatter -------------------------
-        // park the feature gradients in this lane's own LDS column so the level loop can stay a
-        // runtime loop (no barrier: every lane reads back only what it wrote itself)
-        if (dtable) {
+        // d(loss)/d(features) goes to HBM as [point][L*F]; the table scatter is a separate,
+        // atomic-bound launch with its own lane mapping (see scatter_kernel in field_fwd.hip)
+        if (valid) {
+            float* dst = dfeat + p * LF + h * LHF;
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
-                if (t < LHF) SX[t * kSXP + lane + 64 * wave] = x0[t];
-                if (16 + t < LHF) SX[(16 + t) * kSXP + lane + 64 * wave] = x1[t];
-            }
-            for (int j = 0; j < g.LH; ++j) {
-                const LevelP lp = level_params(g, j, h);
-                if (valid && lp.active) {
-                    const Corners c = level_corners(lp, q.x, q.y, q.z);
-#pragma unroll
-                    for (int f = 0; f < F; ++f) {
-                        const float gr = SX[(j * F + f) * kSXP + lane + 64 * wave];
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) atomicAdd(dtable + (size_t)c.idx[k] * F + f, c.w[k] * gr);
-                    }
-                }
+                if (t < LHF && h * LHF + t < LF) dst[t] = x0[t];
+                if (16 + t < LHF && h * LHF + 16 + t < LF) dst[16 + t] = x1[t];
             }
         }
     }
@@ -361,14 +347,14 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
 
 extern "C" int nerf_field_bwd(const NerfGridCfg* grid, const NerfNetCfg* net, const float* table, const float* sigma_params,
                               const float* color_params, const float* latent_emb, int64_t n_images, const NerfPointSrc* src,
-                              const float* x_hashtable, const float* dsigma, const float* drgb, float* dtable,
-                              float* dsigma_params, float* dcolor_params, float* dlatent, void* stream) {
+                              const float* x_hashtable, const float* dsigma, const float* drgb, float* dfeat,
+                              float* dtable, float* dsigma_params, float* dcolor_params, float* dlatent, void* stream) {
     (void)table;
     int rc = nerf_check_cfg("nerf_field_bwd", grid, net, true);
     if (rc) return rc;
     rc = nerf_check_src("nerf_field_bwd", src, true);
     if (rc) return rc;
-    NERF_REQUIRE(sigma_params && color_params && x_hashtable && dsigma && drgb && dsigma_params && dcolor_params,
+    NERF_REQUIRE(sigma_params && color_params && x_hashtable && dsigma && drgb && dfeat && dsigma_params && dcolor_params,
                  "null pointer");
     NERF_REQUIRE(net->latent_dim == 0 || (latent_emb && dlatent && n_images > 0), "latent embedding missing");
     if (src->n_points == 0) return 0;
@@ -378,7 +364,7 @@ extern "C" int nerf_field_bwd(const NerfGridCfg* grid, const NerfNetCfg* net, co
     NERF_UNSUPPORTED(s.in_c > 96 || s.lat > 48, "colour-net input wider than 96 or latent wider than 48");
     int sb_rows = s.in_sp > kHid ? s.in_sp : kHid;
     if (s.in_c > sb_rows) sb_rows = s.in_c;
-    const int lds_bytes = (s.total + kHid * kSP + sb_rows * kSP + (s.in_sp / 2) * kSXP) * (int)sizeof(float);
+    const int lds_bytes = (s.total + kHid * kSP + sb_rows * kSP) * (int)sizeof(float);
     NERF_UNSUPPORTED(lds_bytes > 160 * 1024, "network too large for LDS");
     const int64_t n_btiles = ceil_div64(src->n_points, kBlockPts);
     const unsigned nb = (unsigned)(n_btiles < kNumCU ? n_btiles : kNumCU);
@@ -389,7 +375,7 @@ extern "C" int nerf_field_bwd(const NerfGridCfg* grid, const NerfNetCfg* net, co
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);  \
         if (e != hipSuccess) { nerf_set_error("field_bwd: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }  \
         kern<<<nb, 256, lds_bytes, st>>>(g, s, sigma_params, color_params, latent_emb, *src, x_hashtable, dsigma, drgb, \
-                                         dtable, dsigma_params, dcolor_params, dlatent, sb_rows);                      \
+                                         dfeat, dsigma_params, dcolor_params, dlatent, sb_rows);                       \
     } while (0)
     switch (grid->n_features) {
         case 1: LAUNCH(1); break;
@@ -397,5 +383,7 @@ extern "C" int nerf_field_bwd(const NerfGridCfg* grid, const NerfNetCfg* net, co
         default: LAUNCH(4); break;
     }
 #undef LAUNCH
-    return nerf_launch_status("nerf_field_bwd");
+    rc = nerf_launch_status("nerf_field_bwd");
+    if (rc || !dtable) return rc;
+    return nerf_hashgrid_scatter(grid, src, dfeat, dtable, stream);
 }

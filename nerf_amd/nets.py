@@ -164,9 +164,12 @@ class _FieldFn(torch.autograd.Function):
         else:
             dtable, dsw, dcw = torch.zeros_like(table), torch.zeros_like(sigma_w), torch.zeros_like(color_w)
             dlat = torch.zeros_like(latent) if latent is not None else None
+        dfeat = torch.empty_like(xh)
         check(lib().nerf_field_bwd(C.byref(net.encoder.cfg), C.byref(net.net_cfg), ptr(table), ptr(sigma_w), ptr(color_w),
                                    ptr(latent), net.N, C.byref(src), ptr(xh), ptr(f32(dsigma)), ptr(f32(drgb)),
-                                   ptr(dtable), ptr(dsw), ptr(dcw), ptr(dlat), stream()), 'nerf_field_bwd')
+                                   ptr(dfeat), None, ptr(dsw), ptr(dcw), ptr(dlat), stream()), 'nerf_field_bwd')
+        check(lib().nerf_hashgrid_scatter(C.byref(net.encoder.cfg), C.byref(src), ptr(dfeat), ptr(dtable), stream()),
+              'nerf_hashgrid_scatter')
         if direct:
             return None, None, None, None, None, None, None
         return dtable, dsw, dcw, dlat, None, None, None
