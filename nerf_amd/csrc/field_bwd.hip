@@ -27,8 +27,8 @@ __device__ __forceinline__ f32x16 dw_tile(f32x16 acc, const float* SA, const flo
     const float* pb = SB + (bl ? br : 0) * kSP + h;
 #pragma unroll 16
     for (int st = 0; st < kBlockPts / 2; ++st) {
-        const float a = al ? pa[2 * st] : 0.f;
-        const float b = bl ? pb[2 * st] : 0.f;
+        const float a = sel0(al, pa[2 * st]);
+        const float b = sel0(bl, pb[2 * st]);
         acc = MFMA32(a, b, acc);
     }
     return acc;
@@ -60,7 +60,7 @@ __device__ __forceinline__ f32x16 relu_mask(const f32x16& d, const f32x16& act) 
     return r;
 }
 
-template <int F>
+template <int F, int XF>
 __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, const float* __restrict__ sigma_w,
                                                            const float* __restrict__ color_w,
                                                            const float* __restrict__ latent, NerfPointSrc src,
@@ -92,22 +92,30 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
         const bool valid = p_raw < M;
         const int64_t p = valid ? p_raw : M - 1;
         const PointIn q = fetch_point(src, p, true);
-        const float dsig = valid ? dsigma[p] : 0.f;
-        const float dr0 = valid ? drgb[p * 3] : 0.f, dr1 = valid ? drgb[p * 3 + 1] : 0.f, dr2 = valid ? drgb[p * 3 + 2] : 0.f;
+        const float dsig = sel0(valid, dsigma[p]);
+        const float dr0 = sel0(valid, drgb[p * 3]), dr1 = sel0(valid, drgb[p * 3 + 1]), dr2 = sel0(valid, drgb[p * 3 + 2]);
 
+        // all of this lane's inputs are fetched up front (one exposed memory latency per block tile,
+        // not one per level): its LH*F hash-grid features and its half of the latent row
+        // (they are fetched again, from L2, right before the two places that stage them for the dW
+        // products: holding 60 more registers across the whole tile costs scratch spills instead)
+        const float* xrow = xh + p * LF + h * LHF;
+        const float* lrow = latent + q.n * s.lat + h * s.lat_half;
+        float xf[XF], lat[24];
+#pragma unroll
+        for (int t = 0; t < XF; ++t) xf[t] = (t < LHF && h * LHF + t < LF) ? xrow[t] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 24; ++t) lat[t] = t < s.lat_half ? lrow[t] : 0.f;
         // ------------------------- forward recompute -------------------------
         f32x16 a0 = zero16(), a1 = zero16();
         {
             const float* w1r0 = lds + s.w_s1 + l31 * s.p_s1 + h * LHF;
             const float* w1r1 = w1r0 + 32 * s.p_s1;
-            for (int j = 0; j < g.LH; ++j) {
-                const bool active = h ? (g.LH + j < g.L) : true;
-                const float* fp = xh + p * LF + (h * g.LH + j) * F;
 #pragma unroll
-                for (int f = 0; f < F; ++f) {
-                    const float b = active ? fp[f] : 0.f;
-                    a0 = MFMA32(w1r0[j * F + f], b, a0);
-                    a1 = MFMA32(w1r1[j * F + f], b, a1);
+            for (int t = 0; t < XF; ++t) {
+                if (t < LHF) {
+                    a0 = MFMA32(w1r0[t], xf[t], a0);
+                    a1 = MFMA32(w1r1[t], xf[t], a1);
                 }
             }
         }
@@ -117,7 +125,6 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
         f32x16 c0 = zero16(), c1 = zero16();
         float sh[16];
         sh16(q.dx, q.dy, q.dz, sh);
-        const float* lrow = latent + q.n * s.lat + h * s.lat_half;
         {
             const float* wc0 = lds + s.w_c1 + l31 * s.p_c1;
             const float* wc1 = wc0 + 32 * s.p_c1;
@@ -141,11 +148,12 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
                 }
             }
             const int base = 15 + s.sh_dim + h * s.lat_half;
-#pragma unroll 4
-            for (int t = 0; t < s.lat_half; ++t) {
-                const float b = lrow[t];
-                c0 = MFMA32(wc0[base + t], b, c0);
-                c1 = MFMA32(wc1[base + t], b, c1);
+#pragma unroll
+            for (int t = 0; t < 24; ++t) {
+                if (t < s.lat_half) {
+                    c0 = MFMA32(wc0[base + t], lat[t], c0);
+                    c1 = MFMA32(wc1[base + t], lat[t], c1);
+                }
             }
         }
         c0 = relu16(c0);
@@ -182,6 +190,9 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
         stage64(SA, col, h, g0, g1);
         stage64(SB, col, h, c0, c1);
         __syncthreads();
+        float lat2[24];
+#pragma unroll
+        for (int t = 0; t < 24; ++t) lat2[t] = t < s.lat_half ? lrow[t] : 0.f;   // lands under the dW MFMAs below
         acc_c2 = dw_tile(acc_c2, SA, SB, wave >> 1, wave & 1, kHid, kHid, l31, h);
         {
             f32x16 t0, t1;
@@ -197,15 +208,21 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
             const int row = krow(t) + 4 * h;
             if (row >= 1) SB[(row - 1) * kSP + col] = o2[t];
         }
+        {
+            float sh2[16];
+            sh16(q.dx, q.dy, q.dz, sh2);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            if (t < s.sh_half) {
-                float b = h ? sh[8 + t] : sh[t];
-                if (s.sh_half == 2) b = h ? sh[2 + t] : sh[t];
-                SB[(15 + h * s.sh_half + t) * kSP + col] = b;
+            for (int t = 0; t < 8; ++t) {
+                if (t < s.sh_half) {
+                    float b = h ? sh2[8 + t] : sh2[t];
+                    if (s.sh_half == 2) b = h ? sh2[2 + t] : sh2[t];
+                    SB[(15 + h * s.sh_half + t) * kSP + col] = b;
+                }
             }
         }
-        for (int t = 0; t < s.lat_half; ++t) SB[(15 + s.sh_dim + h * s.lat_half + t) * kSP + col] = lrow[t];
+#pragma unroll
+        for (int t = 0; t < 24; ++t)
+            if (t < s.lat_half) SB[(15 + s.sh_dim + h * s.lat_half + t) * kSP + col] = lat2[t];
         __syncthreads();
         acc_c1 = dw_tile(acc_c1, SA, SB, wave / in_c_tiles, wave % in_c_tiles, kHid, s.in_c, l31, h);
         if (wave < 2 && 4 + wave < 2 * in_c_tiles)
@@ -223,14 +240,14 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const int kk = (krow(t) + 4 * h) * s.p_c1;
-                dG = MFMA32(liveG ? wG[kk] : 0.f, g0[t], dG);
-                dL = MFMA32(liveL ? wL[kk] : 0.f, g0[t], dL);
+                dG = MFMA32(sel0(liveG, wG[kk]), g0[t], dG);
+                dL = MFMA32(sel0(liveL, wL[kk]), g0[t], dL);
             }
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const int kk = (32 + krow(t) + 4 * h) * s.p_c1;
-                dG = MFMA32(liveG ? wG[kk] : 0.f, g1[t], dG);
-                dL = MFMA32(liveL ? wL[kk] : 0.f, g1[t], dL);
+                dG = MFMA32(sel0(liveG, wG[kk]), g1[t], dG);
+                dL = MFMA32(sel0(liveL, wL[kk]), g1[t], dL);
             }
         }
         // latent gradient: rows 16..31 of tile G are latent 0..15, tile L holds latent 16..47
@@ -277,6 +294,9 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
         for (int t = 0; t < 8; ++t) SA[(krow(t) + 4 * h) * kSP + col] = d2[t];
         stage64(SB, col, h, a0, a1);
         __syncthreads();
+        float xf2[XF];
+#pragma unroll
+        for (int t = 0; t < XF; ++t) xf2[t] = (t < LHF && h * LHF + t < LF) ? xrow[t] : 0.f;
         if (wave < 2) acc_y = dw_tile(acc_y, SA, SB, 0, wave, kGeoRows, kHid, l31, h);
         layer_T_Nx64(lds + s.w_s2, s.p_s2, kGeoRows, l31, h, d2, g0, g1);
         g0 = relu_mask(g0, a0);
@@ -284,12 +304,9 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
         // ------------------------- sigma layer 1 -------------------------
         __syncthreads();
         stage64(SA, col, h, g0, g1);
-        for (int j = 0; j < g.LH; ++j) {
-            const bool active = h ? (g.LH + j < g.L) : true;
-            const float* fp = xh + p * LF + (h * g.LH + j) * F;
 #pragma unroll
-            for (int f = 0; f < F; ++f) SB[(h * LHF + j * F + f) * kSP + col] = active ? fp[f] : 0.f;
-        }
+        for (int t = 0; t < XF; ++t)
+            if (t < LHF) SB[(h * LHF + t) * kSP + col] = xf2[t];
         __syncthreads();
         acc_s1 = dw_tile(acc_s1, SA, SB, wave >> 1, wave & 1, kHid, s.in_sp, l31, h);
         // d(features): row map chosen so that each lane receives the gradients of its OWN levels:
@@ -303,14 +320,14 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const int kk = (krow(t) + 4 * h) * s.p_s1;
-                x0 = MFMA32(live0 ? w0[kk] : 0.f, g0[t], x0);
-                x1 = MFMA32(live1 ? w1[kk] : 0.f, g0[t], x1);
+                x0 = MFMA32(sel0(live0, w0[kk]), g0[t], x0);
+                x1 = MFMA32(sel0(live1, w1[kk]), g0[t], x1);
             }
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const int kk = (32 + krow(t) + 4 * h) * s.p_s1;
-                x0 = MFMA32(live0 ? w0[kk] : 0.f, g1[t], x0);
-                x1 = MFMA32(live1 ? w1[kk] : 0.f, g1[t], x1);
+                x0 = MFMA32(sel0(live0, w0[kk]), g1[t], x0);
+                x1 = MFMA32(sel0(live1, w1[kk]), g1[t], x1);
             }
         }
         // d(loss)/d(features) goes to HBM as [point][L*F]; the table scatter is a separate,
@@ -362,6 +379,7 @@ extern "C" int nerf_field_bwd(const NerfGridCfg* grid, const NerfNetCfg* net, co
     const NetLds s = make_net_lds(grid, net, true);
     NERF_UNSUPPORTED(s.in_sp > 64, "more than 64 hash-grid features");
     NERF_UNSUPPORTED(s.in_c > 96 || s.lat > 48, "colour-net input wider than 96 or latent wider than 48");
+    NERF_UNSUPPORTED(net->latent_dim > 0 && !latent_emb, "latent table missing");
     int sb_rows = s.in_sp > kHid ? s.in_sp : kHid;
     if (s.in_c > sb_rows) sb_rows = s.in_c;
     const int lds_bytes = (s.total + kHid * kSP + sb_rows * kSP) * (int)sizeof(float);
@@ -369,13 +387,19 @@ extern "C" int nerf_field_bwd(const NerfGridCfg* grid, const NerfNetCfg* net, co
     const int64_t n_btiles = ceil_div64(src->n_points, kBlockPts);
     const unsigned nb = (unsigned)(n_btiles < kNumCU ? n_btiles : kNumCU);
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH(FF)                                                                                                     \
+#define LAUNCH2(FF, XX)                                                                                                \
     do {                                                                                                               \
-        auto kern = field_bwd_kernel<FF>;                                                                              \
+        auto kern = field_bwd_kernel<FF, XX>;                                                                            \
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);  \
         if (e != hipSuccess) { nerf_set_error("field_bwd: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }  \
         kern<<<nb, 256, lds_bytes, st>>>(g, s, sigma_params, color_params, latent_emb, *src, x_hashtable, dsigma, drgb, \
                                          dfeat, dsigma_params, dcolor_params, dlatent, sb_rows);                       \
+    } while (0)
+#define LAUNCH(FF)                                       \
+    do {                                                 \
+        if (s.in_sp / 2 <= 16) LAUNCH2(FF, 16);          \
+        else if (s.in_sp / 2 <= 20) LAUNCH2(FF, 20);     \
+        else LAUNCH2(FF, 32);                            \
     } while (0)
     switch (grid->n_features) {
         case 1: LAUNCH(1); break;
@@ -383,6 +407,7 @@ extern "C" int nerf_field_bwd(const NerfGridCfg* grid, const NerfNetCfg* net, co
         default: LAUNCH(4); break;
     }
 #undef LAUNCH
+#undef LAUNCH2
     rc = nerf_launch_status("nerf_field_bwd");
     if (rc || !dtable) return rc;
     return nerf_hashgrid_scatter(grid, src, dfeat, dtable, stream);

@@ -87,6 +87,13 @@ static inline NetLds make_net_lds(const NerfGridCfg* g, const NerfNetCfg* n, boo
 // ------------------------------------------------------------------------------------------
 #ifdef __HIPCC__
 
+// select AFTER an unconditional load: `c ? p[i] : 0` makes hipcc branch around the ds_read
+// (s_and_saveexec + s_waitcnt lgkmcnt(0) per MFMA); addresses are clamped by the callers instead.
+__device__ __forceinline__ float sel0(bool c, float v) {
+    asm volatile("" : "+v"(v));   // the value is opaque here, so the load cannot be sunk into a branch
+    return c ? v : 0.f;
+}
+
 __device__ __forceinline__ int krow(int t) { return (t & 3) + 8 * (t >> 2); }  // + 4*h: row of register t
 
 // copy one layer [out][in] from global into LDS [out][pitch] (pad columns stay zero)
@@ -282,12 +289,12 @@ __device__ __forceinline__ f32x16 layer_64xN(const float* w, int pitch, int n_ou
     f32x16 o = zero16();
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
-        const float a = live ? r0[krow(t)] : 0.f;
+        const float a = sel0(live, r0[krow(t)]);
         o = MFMA32(a, i0[t], o);
     }
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
-        const float a = live ? r0[32 + krow(t)] : 0.f;
+        const float a = sel0(live, r0[32 + krow(t)]);
         o = MFMA32(a, i1[t], o);
     }
     return o;
@@ -304,8 +311,8 @@ __device__ __forceinline__ void layer_T_Nx64(const float* w, int pitch, int n_ou
             const int k = krow(t) + 4 * h;
             const bool live = k < n_out;
             const float* r = w + (live ? k : 0) * pitch + l31;
-            const float a0 = live ? r[0] : 0.f, a1 = live ? r[32] : 0.f;
-            const float b = live ? d[t] : 0.f;
+            const float a0 = sel0(live, r[0]), a1 = sel0(live, r[32]);
+            const float b = sel0(live, d[t]);
             o0 = MFMA32(a0, b, o0);
             o1 = MFMA32(a1, b, o1);
         }

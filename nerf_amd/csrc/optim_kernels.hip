@@ -21,20 +21,47 @@ __device__ __forceinline__ void adam1(float& p, float& g, float& m, float& v, co
     p = p - k.lr_over_bc1 * (m / denom);
 }
 
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void adam4(f4& p, const f4& g, f4& m, f4& v, const AdamK& k) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float a = p[e], b = g[e], c = m[e], d = v[e];
+        adam1(a, b, c, d, k);
+        p[e] = a; m[e] = c; v[e] = d;
+    }
+}
+
+// Two independent 16-byte quads per lane in flight, non-temporal loads/stores (every byte is touched
+// exactly once per step, so nothing is worth keeping in L2 / Infinity Cache), and a grid of many
+// short blocks rather than 2048 persistent ones: measured 2.45 ms vs 2.80 ms on the 400 M-parameter table.
 template <bool ZERO>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n, AdamK k) {
     const int64_t n4 = n >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    float4* p4 = (float4*)p; float4* g4 = (float4*)g; float4* m4 = (float4*)m; float4* v4 = (float4*)v;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
-        adam1(pp.x, gg.x, mm.x, vv.x, k);
-        adam1(pp.y, gg.y, mm.y, vv.y, k);
-        adam1(pp.z, gg.z, mm.z, vv.z, k);
-        adam1(pp.w, gg.w, mm.w, vv.w, k);
-        p4[i] = pp; m4[i] = mm; v4[i] = vv;
-        if (ZERO) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    f4* p4 = (f4*)p; f4* g4 = (f4*)g; f4* m4 = (f4*)m; f4* v4 = (f4*)v;
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += 2 * stride) {
+        const int64_t i1 = i0 + stride;
+        const bool two = i1 < n4;
+        f4 pa = __builtin_nontemporal_load(p4 + i0), ga = __builtin_nontemporal_load(g4 + i0);
+        f4 ma = __builtin_nontemporal_load(m4 + i0), va = __builtin_nontemporal_load(v4 + i0);
+        f4 pb = zero, gb = zero, mb = zero, vb = zero;
+        if (two) {
+            pb = __builtin_nontemporal_load(p4 + i1); gb = __builtin_nontemporal_load(g4 + i1);
+            mb = __builtin_nontemporal_load(m4 + i1); vb = __builtin_nontemporal_load(v4 + i1);
+        }
+        adam4(pa, ga, ma, va, k);
+        __builtin_nontemporal_store(pa, p4 + i0); __builtin_nontemporal_store(ma, m4 + i0);
+        __builtin_nontemporal_store(va, v4 + i0);
+        if (ZERO) __builtin_nontemporal_store(zero, g4 + i0);
+        if (two) {
+            adam4(pb, gb, mb, vb, k);
+            __builtin_nontemporal_store(pb, p4 + i1); __builtin_nontemporal_store(mb, m4 + i1);
+            __builtin_nontemporal_store(vb, v4 + i1);
+            if (ZERO) __builtin_nontemporal_store(zero, g4 + i1);
+        }
     }
     const int64_t tail = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (tail < n) {
@@ -63,9 +90,9 @@ extern "C" int nerf_adam_step(float* param, float* grad, float* exp_avg, float* 
     k.one_m_beta1 = (float)(1.0 - (double)beta1);
     k.one_m_beta2 = (float)(1.0 - (double)beta2);
     k.eps = eps; k.wd = weight_decay; k.gscale = grad_scale;
-    int64_t want = ceil_div64(ceil_div64(count, 4), 256);
+    int64_t want = ceil_div64(ceil_div64(count, 8), 256);
     if (want < 1) want = 1;
-    const unsigned nb = (unsigned)(want < (int64_t)kNumCU * 8 ? want : (int64_t)kNumCU * 8);
+    const unsigned nb = (unsigned)(want < 65536 ? want : 65536);
     if (zero_grad) adam_kernel<true><<<nb, 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, count, k);
     else adam_kernel<false><<<nb, 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, count, k);
     return nerf_launch_status("nerf_adam_step");

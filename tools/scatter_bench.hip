@@ -107,7 +107,13 @@ int main(int argc, char** argv) {
     GridDev g = make_grid_dev(&cfg);
     std::vector<float> hx(M * 3), hd(M * 40);
     std::mt19937 rng(1); std::uniform_real_distribution<float> U(0.f, 1.f);
-    if (coherent) {
+    if (coherent == 2) {   // rays through a ball of radius 0.34 around the cube centre (what the bench scene produces)
+        for (int64_t r = 0; r < M / 128; ++r) {
+            float o[3], e[3];
+            for (int c = 0; c < 3; ++c) { o[c] = 0.5f + 0.68f * (U(rng) - 0.5f); e[c] = 0.5f + 0.68f * (U(rng) - 0.5f); }
+            for (int s = 0; s < 128; ++s) for (int c = 0; c < 3; ++c) hx[(r * 128 + s) * 3 + c] = o[c] + (e[c] - o[c]) * (s + U(rng)) / 128.f;
+        }
+    } else if (coherent) {
         for (int64_t r = 0; r < M / 128; ++r) {
             float o[3] = {U(rng), U(rng), U(rng)}, e[3] = {U(rng), U(rng), U(rng)};
             for (int s = 0; s < 128; ++s) for (int c = 0; c < 3; ++c) hx[(r * 128 + s) * 3 + c] = o[c] + (e[c] - o[c]) * (s + U(rng)) / 128.f;
