@@ -25,11 +25,18 @@ __device__ __forceinline__ f32x16 dw_tile(f32x16 acc, const float* SA, const flo
     const bool al = ar < n_out, bl = br < n_in;
     const float* pa = SA + (al ? ar : 0) * kSP + h;
     const float* pb = SB + (bl ? br : 0) * kSP + h;
-#pragma unroll 16
-    for (int st = 0; st < kBlockPts / 2; ++st) {
-        const float a = sel0(al, pa[2 * st]);
-        const float b = sel0(bl, pb[2 * st]);
-        acc = MFMA32(a, b, acc);
+    constexpr int G = 4, NG = kBlockPts / 2 / G;
+    float abuf[2][G], bbuf[2][G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) { abuf[0][i] = pa[2 * i]; bbuf[0][i] = pb[2 * i]; }
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+        if (gi + 1 < NG) {
+#pragma unroll
+            for (int i = 0; i < G; ++i) { abuf[(gi + 1) & 1][i] = pa[2 * ((gi + 1) * G + i)]; bbuf[(gi + 1) & 1][i] = pb[2 * ((gi + 1) * G + i)]; }
+        }
+#pragma unroll
+        for (int i = 0; i < G; ++i) acc = MFMA32(sel0(al, abuf[gi & 1][i]), sel0(bl, bbuf[gi & 1][i]), acc);
     }
     return acc;
 }
@@ -107,62 +114,32 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
 #pragma unroll
         for (int t = 0; t < 24; ++t) lat[t] = t < s.lat_half ? lrow[t] : 0.f;
         // ------------------------- forward recompute -------------------------
-        f32x16 a0 = zero16(), a1 = zero16();
+        f32x16 a0, a1;
         {
-            const float* w1r0 = lds + s.w_s1 + l31 * s.p_s1 + h * LHF;
-            const float* w1r1 = w1r0 + 32 * s.p_s1;
-#pragma unroll
-            for (int t = 0; t < XF; ++t) {
-                if (t < LHF) {
-                    a0 = MFMA32(w1r0[t], xf[t], a0);
-                    a1 = MFMA32(w1r1[t], xf[t], a1);
-                }
-            }
+            const float* w1r0 = lds + kWS1 + l31 * kPS1 + h * LHF;
+            const float* w1r1 = w1r0 + 32 * kPS1;
+            f32x16 acc[2] = {zero16(), zero16()};
+            // steps past LH*F (generic XF = 32 build) multiply by xf = 0
+            mfma_chain<XF, 2>(acc, [&](int t, int n) { return (n ? w1r1 : w1r0)[t < LHF ? t : 0]; }, [&](int t) { return xf[t % XF]; });
+            a0 = acc[0];
+            a1 = acc[1];
         }
         a0 = relu16(a0);
         a1 = relu16(a1);
-        const f32x16 o2 = layer_64xN(lds + s.w_s2, s.p_s2, kGeoRows, l31, h, a0, a1);
-        f32x16 c0 = zero16(), c1 = zero16();
-        float sh[16];
-        sh16(q.dx, q.dy, q.dz, sh);
+        const f32x16 o2 = layer_64xN<kPS2>(lds + kWS2, kGeoRows, l31, h, a0, a1);
+        f32x16 c0, c1;
         {
-            const float* wc0 = lds + s.w_c1 + l31 * s.p_c1;
-            const float* wc1 = wc0 + 32 * s.p_c1;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int row = krow(t) + 4 * h;
-                const bool is_sigma = row == 0;
-                const int in = is_sigma ? 0 : row - 1;
-                const float b = is_sigma ? 0.f : o2[t];
-                c0 = MFMA32(wc0[in], b, c0);
-                c1 = MFMA32(wc1[in], b, c1);
-            }
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                if (t < s.sh_half) {
-                    float b = h ? sh[8 + t] : sh[t];
-                    if (s.sh_half == 2) b = h ? sh[2 + t] : sh[t];
-                    const int in = 15 + h * s.sh_half + t;
-                    c0 = MFMA32(wc0[in], b, c0);
-                    c1 = MFMA32(wc1[in], b, c1);
-                }
-            }
-            const int base = 15 + s.sh_dim + h * s.lat_half;
-#pragma unroll
-            for (int t = 0; t < 24; ++t) {
-                if (t < s.lat_half) {
-                    c0 = MFMA32(wc0[base + t], lat[t], c0);
-                    c1 = MFMA32(wc1[base + t], lat[t], c1);
-                }
-            }
+            float sh[16];
+            sh16(q.dx, q.dy, q.dz, sh);
+            color_layer1(lds, s, l31, h, o2, sh, lat, c0, c1);
         }
         c0 = relu16(c0);
         c1 = relu16(c1);
         f32x16 e0, e1;
-        layer_64x64(lds + s.w_c2, s.p_c2, l31, h, c0, c1, e0, e1);
+        layer_64x64<kPC2>(lds + kWC2, l31, h, c0, c1, e0, e1);
         e0 = relu16(e0);
         e1 = relu16(e1);
-        const f32x16 o3 = layer_64xN(lds + s.w_c3, s.p_c3, 3, l31, h, e0, e1);
+        const f32x16 o3 = layer_64xN<kPC3>(lds + kWC3, 3, l31, h, e0, e1);
 
         // ------------------------- colour layer 3 -------------------------
         f32x16 d3 = zero16();
@@ -182,7 +159,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
         __syncthreads();
         if (wave >= 2) acc_y = dw_tile(acc_y, SA, SB, 0, wave - 2, 3, kHid, l31, h);
         f32x16 g0, g1;
-        layer_T_Nx64(lds + s.w_c3, s.p_c3, 3, l31, h, d3, g0, g1);
+        layer_T_Nx64<3, kPC3>(lds + kWC3, 3, l31, h, d3, g0, g1);
         g0 = relu_mask(g0, e0);
         g1 = relu_mask(g1, e1);
         // ------------------------- colour layer 2 -------------------------
@@ -196,7 +173,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
         acc_c2 = dw_tile(acc_c2, SA, SB, wave >> 1, wave & 1, kHid, kHid, l31, h);
         {
             f32x16 t0, t1;
-            layer_T_64x64(lds + s.w_c2, s.p_c2, l31, h, g0, g1, t0, t1);
+            layer_T_64x64<kPC2>(lds + kWC2, l31, h, g0, g1, t0, t1);
             g0 = relu_mask(t0, c0);
             g1 = relu_mask(t1, c1);
         }
@@ -235,20 +212,17 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
             const bool liveG = l31 < 16 ? (l31 >= 1) : (l31 - 16 < s.lat);
             const int inL = lat0 + 16 + l31;
             const bool liveL = 16 + l31 < s.lat;
-            const float* wG = lds + s.w_c1 + (liveG ? inG : 0);
-            const float* wL = lds + s.w_c1 + (liveL ? inL : 0);
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int kk = (krow(t) + 4 * h) * s.p_c1;
-                dG = MFMA32(sel0(liveG, wG[kk]), g0[t], dG);
-                dL = MFMA32(sel0(liveL, wL[kk]), g0[t], dL);
-            }
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int kk = (32 + krow(t) + 4 * h) * s.p_c1;
-                dG = MFMA32(sel0(liveG, wG[kk]), g1[t], dG);
-                dL = MFMA32(sel0(liveL, wL[kk]), g1[t], dL);
-            }
+            const float* wG = lds + kWC1 + (liveG ? inG : 0);
+            const float* wL = lds + kWC1 + (liveL ? inL : 0);
+            f32x16 acc[2] = {zero16(), zero16()};
+            mfma_chain<32, 2>(acc,
+                              [&](int st, int n) {
+                                  const int kk = (krow64(st) + 4 * h) * kPC1;
+                                  return n ? sel0(liveL, wL[kk]) : sel0(liveG, wG[kk]);
+                              },
+                              [&](int st) { return st < 16 ? g0[st & 15] : g1[st & 15]; });
+            dG = acc[0];
+            dL = acc[1];
         }
         // latent gradient: rows 16..31 of tile G are latent 0..15, tile L holds latent 16..47
         if (s.lat > 0) {
@@ -298,7 +272,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
 #pragma unroll
         for (int t = 0; t < XF; ++t) xf2[t] = (t < LHF && h * LHF + t < LF) ? xrow[t] : 0.f;
         if (wave < 2) acc_y = dw_tile(acc_y, SA, SB, 0, wave, kGeoRows, kHid, l31, h);
-        layer_T_Nx64(lds + s.w_s2, s.p_s2, kGeoRows, l31, h, d2, g0, g1);
+        layer_T_Nx64<8, kPS2>(lds + kWS2, kGeoRows, l31, h, d2, g0, g1);
         g0 = relu_mask(g0, a0);
         g1 = relu_mask(g1, a1);
         // ------------------------- sigma layer 1 -------------------------
@@ -315,20 +289,17 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
         {
             const int hh = (l31 >> 2) & 1, qq = (l31 & 3) + 4 * (l31 >> 3);
             const bool live0 = qq < LHF, live1 = 16 + qq < LHF;
-            const float* w0 = lds + s.w_s1 + (live0 ? hh * LHF + qq : 0);
-            const float* w1 = lds + s.w_s1 + (live1 ? hh * LHF + 16 + qq : 0);
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int kk = (krow(t) + 4 * h) * s.p_s1;
-                x0 = MFMA32(sel0(live0, w0[kk]), g0[t], x0);
-                x1 = MFMA32(sel0(live1, w1[kk]), g0[t], x1);
-            }
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int kk = (32 + krow(t) + 4 * h) * s.p_s1;
-                x0 = MFMA32(sel0(live0, w0[kk]), g1[t], x0);
-                x1 = MFMA32(sel0(live1, w1[kk]), g1[t], x1);
-            }
+            const float* w0 = lds + kWS1 + (live0 ? hh * LHF + qq : 0);
+            const float* w1 = lds + kWS1 + (live1 ? hh * LHF + 16 + qq : 0);
+            f32x16 acc[2] = {zero16(), zero16()};
+            mfma_chain<32, 2>(acc,
+                              [&](int st, int n) {
+                                  const int kk = (krow64(st) + 4 * h) * kPS1;
+                                  return n ? sel0(live1, w1[kk]) : sel0(live0, w0[kk]);
+                              },
+                              [&](int st) { return st < 16 ? g0[st & 15] : g1[st & 15]; });
+            x0 = acc[0];
+            x1 = acc[1];
         }
         // d(loss)/d(features) goes to HBM as [point][L*F]; the table scatter is a separate,
         // atomic-bound launch with its own lane mapping (see scatter_kernel in field_fwd.hip)

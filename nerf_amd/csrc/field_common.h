@@ -33,17 +33,25 @@ struct GridDev {
 // LDS image of the network weights: every layer row-major [out][pitch] with an ODD pitch, which
 // makes both the forward read (lanes walk `out`) and the backward read (lanes walk `in`)
 // bank-conflict free for ds_read_b32.
+// Pitches and offsets are COMPILE-TIME constants (sized for the widest supported inputs: 64 hash-grid
+// features, 96 colour-net inputs): with a run-time pitch every transposed read needs its own address
+// VGPR, hipcc hoists all of them out of the tile loop and the kernel drowns in spills; with constants
+// they fold into the 16-bit immediate offset of ds_read.
+constexpr int kPS1 = 65, kPS2 = 65, kPC1 = 97, kPC2 = 65, kPC3 = 65;
+constexpr int kWS1 = 0;
+constexpr int kWS2 = kWS1 + kHid * kPS1;
+constexpr int kWC1 = kWS2 + kGeoRows * kPS2;
+constexpr int kWC2 = kWC1 + kHid * kPC1;
+constexpr int kWC3 = kWC2 + kHid * kPC2;
+constexpr int kNetLdsSigma = kWC1;              // floats: sigma net only
+constexpr int kNetLdsFull = kWC3 + 3 * kPC3;    // floats: both nets
+
 struct NetLds {
     int in_s;    // L*F
     int in_sp;   // 2*LH*F (internal, zero padded when L is odd)
     int in_c;    // 15 + sh_dim + latent
     int sh_dim, sh_half, lat, lat_half;
-    int w_s1, p_s1;  // [64][p_s1]
-    int w_s2, p_s2;  // [16][65]
-    int w_c1, p_c1;  // [64][p_c1]
-    int w_c2, p_c2;  // [64][65]
-    int w_c3, p_c3;  // [3][65]
-    int total;       // floats
+    int total;   // floats of LDS used by the weights
 };
 
 static inline GridDev make_grid_dev(const NerfGridCfg* g) {
@@ -70,15 +78,7 @@ static inline NetLds make_net_lds(const NerfGridCfg* g, const NerfNetCfg* n, boo
     s.lat = n->latent_dim;
     s.lat_half = s.lat / 2;
     s.in_c = n->geo_feat_dim + s.sh_dim + s.lat;
-    int off = 0;
-    s.w_s1 = off; s.p_s1 = s.in_sp | 1; off += kHid * s.p_s1;
-    s.w_s2 = off; s.p_s2 = kHid | 1;    off += kGeoRows * s.p_s2;
-    if (with_color) {
-        s.w_c1 = off; s.p_c1 = s.in_c | 1; off += kHid * s.p_c1;
-        s.w_c2 = off; s.p_c2 = kHid | 1;   off += kHid * s.p_c2;
-        s.w_c3 = off; s.p_c3 = kHid | 1;   off += 3 * s.p_c3;
-    }
-    s.total = off;
+    s.total = with_color ? kNetLdsFull : kNetLdsSigma;
     return s;
 }
 
@@ -108,12 +108,12 @@ __device__ __forceinline__ void lds_load_net(float* lds, const NetLds& s, const 
                                              const float* __restrict__ cw, bool with_color) {
     for (int i = threadIdx.x; i < s.total; i += blockDim.x) lds[i] = 0.f;
     __syncthreads();
-    lds_load_layer(lds + s.w_s1, s.p_s1, sw, kHid, s.in_s);
-    lds_load_layer(lds + s.w_s2, s.p_s2, sw + kHid * s.in_s, kGeoRows, kHid);
+    lds_load_layer(lds + kWS1, kPS1, sw, kHid, s.in_s);
+    lds_load_layer(lds + kWS2, kPS2, sw + kHid * s.in_s, kGeoRows, kHid);
     if (with_color) {
-        lds_load_layer(lds + s.w_c1, s.p_c1, cw, kHid, s.in_c);
-        lds_load_layer(lds + s.w_c2, s.p_c2, cw + kHid * s.in_c, kHid, kHid);
-        lds_load_layer(lds + s.w_c3, s.p_c3, cw + kHid * s.in_c + kHid * kHid, 3, kHid);
+        lds_load_layer(lds + kWC1, kPC1, cw, kHid, s.in_c);
+        lds_load_layer(lds + kWC2, kPC2, cw + kHid * s.in_c, kHid, kHid);
+        lds_load_layer(lds + kWC3, kPC3, cw + kHid * s.in_c + kHid * kHid, 3, kHid);
     }
     __syncthreads();
 }
@@ -260,82 +260,119 @@ __device__ __forceinline__ f32x16 zero16() {
     return v;
 }
 
+// Software-pipelined MFMA chain: acc[n] += A(step, n) * B(step), step = 0 .. STEPS-1.
+// A comes from LDS, B from registers.  hipcc otherwise emits {ds_read; s_waitcnt lgkmcnt(0); mfma} per
+// step, which exposes the LDS latency on every 64-cycle MFMA when only one wave lives on the SIMD;
+// here the reads of group g+1 are issued (in program order) before the MFMAs of group g.
+template <int STEPS, int NT, class AFn, class BFn>
+__device__ __forceinline__ void mfma_chain(f32x16 (&acc)[NT], AFn a_at, BFn b_at) {
+    constexpr int G = 4;
+    float buf[2][G * NT];
+#pragma unroll
+    for (int s = 0; s < G; ++s)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+            if (s < STEPS) buf[0][s * NT + n] = a_at(s, n);
+#pragma unroll
+    for (int g = 0; g * G < STEPS; ++g) {
+#pragma unroll
+        for (int s = 0; s < G; ++s)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                if ((g + 1) * G + s < STEPS) buf[(g + 1) & 1][s * NT + n] = a_at((g + 1) * G + s, n);
+#pragma unroll
+        for (int s = 0; s < G; ++s)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                if (g * G + s < STEPS) acc[n] = MFMA32(buf[g & 1][s * NT + n], b_at(g * G + s), acc[n]);
+    }
+}
+
+// k index (before the +4h of the lane half) of chain step s over a 64-row P-layout pair
+__device__ __forceinline__ constexpr int krow64(int s) { return s < 16 ? krow(s) : 32 + krow(s - 16); }
+
 // out(64) = W[64][64] * in(64): forward through one hidden->hidden layer (P layout in and out)
-__device__ __forceinline__ void layer_64x64(const float* w, int pitch, int l31, int h, const f32x16& i0,
+template <int pitch>
+__device__ __forceinline__ void layer_64x64(const float* w, int l31, int h, const f32x16& i0,
                                             const f32x16& i1, f32x16& o0, f32x16& o1) {
     const float* r0 = w + l31 * pitch + 4 * h;
     const float* r1 = r0 + 32 * pitch;
-    o0 = zero16();
-    o1 = zero16();
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const int k = krow(t);
-        o0 = MFMA32(r0[k], i0[t], o0);
-        o1 = MFMA32(r1[k], i0[t], o1);
-    }
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const int k = 32 + krow(t);
-        o0 = MFMA32(r0[k], i1[t], o0);
-        o1 = MFMA32(r1[k], i1[t], o1);
-    }
+    f32x16 acc[2] = {zero16(), zero16()};
+    mfma_chain<32, 2>(acc, [&](int s, int n) { return (n ? r1 : r0)[krow64(s)]; },
+                      [&](int s) { return s < 16 ? i0[s & 15] : i1[s & 15]; });
+    o0 = acc[0];
+    o1 = acc[1];
 }
 
 // out(rows < n_out <= 32) = W[n_out][64] * in(64)
-__device__ __forceinline__ f32x16 layer_64xN(const float* w, int pitch, int n_out, int l31, int h, const f32x16& i0,
+template <int pitch>
+__device__ __forceinline__ f32x16 layer_64xN(const float* w, int n_out, int l31, int h, const f32x16& i0,
                                              const f32x16& i1) {
     const bool live = l31 < n_out;
     const float* r0 = w + (live ? l31 : 0) * pitch + 4 * h;
-    f32x16 o = zero16();
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const float a = sel0(live, r0[krow(t)]);
-        o = MFMA32(a, i0[t], o);
-    }
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const float a = sel0(live, r0[32 + krow(t)]);
-        o = MFMA32(a, i1[t], o);
-    }
-    return o;
+    f32x16 acc[1] = {zero16()};
+    mfma_chain<32, 1>(acc, [&](int s, int) { return sel0(live, r0[krow64(s)]); },
+                      [&](int s) { return s < 16 ? i0[s & 15] : i1[s & 15]; });
+    return acc[0];
 }
 
-// d_in(64) = W^T * d_out where d_out has n_out (<= 32) live rows in P layout.
-__device__ __forceinline__ void layer_T_Nx64(const float* w, int pitch, int n_out, int l31, int h, const f32x16& d,
+// d_in(64) = W^T * d_out where d_out has n_out live rows held in registers t < NSTEPS
+// (n_out = 16 -> NSTEPS 8, n_out = 3 -> NSTEPS 3).
+template <int NSTEPS, int pitch>
+__device__ __forceinline__ void layer_T_Nx64(const float* w, int n_out, int l31, int h, const f32x16& d,
                                              f32x16& o0, f32x16& o1) {
-    o0 = zero16();
-    o1 = zero16();
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        if (krow(t) < n_out) {  // compile-time after unrolling when n_out is a literal
-            const int k = krow(t) + 4 * h;
-            const bool live = k < n_out;
-            const float* r = w + (live ? k : 0) * pitch + l31;
-            const float a0 = sel0(live, r[0]), a1 = sel0(live, r[32]);
-            const float b = sel0(live, d[t]);
-            o0 = MFMA32(a0, b, o0);
-            o1 = MFMA32(a1, b, o1);
-        }
-    }
+    f32x16 acc[2] = {zero16(), zero16()};
+    mfma_chain<NSTEPS, 2>(acc,
+                          [&](int s, int n) {
+                              const int k = krow(s) + 4 * h;
+                              const bool live = k < n_out;
+                              return sel0(live, w[(live ? k : 0) * pitch + l31 + 32 * n]);
+                          },
+                          [&](int s) { return sel0(krow(s) + 4 * h < n_out, d[s & 15]); });
+    o0 = acc[0];
+    o1 = acc[1];
 }
 
 // d_in(64) = W[64][64]^T * d_out(64)
-__device__ __forceinline__ void layer_T_64x64(const float* w, int pitch, int l31, int h, const f32x16& d0,
+template <int pitch>
+__device__ __forceinline__ void layer_T_64x64(const float* w, int l31, int h, const f32x16& d0,
                                               const f32x16& d1, f32x16& o0, f32x16& o1) {
-    o0 = zero16();
-    o1 = zero16();
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const float* r = w + (krow(t) + 4 * h) * pitch + l31;
-        o0 = MFMA32(r[0], d0[t], o0);
-        o1 = MFMA32(r[32], d0[t], o1);
-    }
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const float* r = w + (32 + krow(t) + 4 * h) * pitch + l31;
-        o0 = MFMA32(r[0], d1[t], o0);
-        o1 = MFMA32(r[32], d1[t], o1);
-    }
+    const float* r = w + 4 * h * pitch + l31;
+    f32x16 acc[2] = {zero16(), zero16()};
+    mfma_chain<32, 2>(acc, [&](int s, int n) { return r[krow64(s) * pitch + 32 * n]; },
+                      [&](int s) { return s < 16 ? d0[s & 15] : d1[s & 15]; });
+    o0 = acc[0];
+    o1 = acc[1];
+}
+
+// Colour layer 1 on [geo(15) | SH | latent]: 8 + 8 + 24 k-steps, the two lane halves splitting every
+// group (inactive steps of smaller configurations multiply by zero).  o2 = sigma-net output rows.
+__device__ __forceinline__ void color_layer1(const float* lds, const NetLds& s, int l31, int h, const f32x16& o2,
+                                             const float (&sh)[16], const float (&lat)[24], f32x16& c0, f32x16& c1) {
+    const float* wc0 = lds + kWC1 + l31 * kPC1;
+    const float* wc1 = wc0 + 32 * kPC1;
+    const int sh_base = 15 + h * s.sh_half, lat_base = 15 + s.sh_dim + h * s.lat_half;
+    f32x16 acc[2] = {zero16(), zero16()};
+    mfma_chain<40, 2>(
+        acc,
+        [&](int st, int n) {
+            int in;
+            if (st < 8) { const int row = krow(st) + 4 * h; in = row == 0 ? 0 : row - 1; }
+            else if (st < 16) in = (st - 8 < s.sh_half) ? sh_base + (st - 8) : 0;
+            else in = (st - 16 < s.lat_half) ? lat_base + (st - 16) : 0;
+            return (n ? wc1 : wc0)[in];
+        },
+        [&](int st) {
+            if (st < 8) return (krow(st) + 4 * h == 0) ? 0.f : o2[st & 7];
+            if (st < 16) {
+                const int t = st - 8;
+                const float v = s.sh_half == 2 ? (h ? sh[(2 + t) & 15] : sh[t]) : (h ? sh[(8 + t) & 15] : sh[t]);
+                return t < s.sh_half ? v : 0.f;
+            }
+            return (st - 16 < s.lat_half) ? lat[(st - 16) % 24] : 0.f;
+        });
+    c0 = acc[0];
+    c1 = acc[1];
 }
 
 #endif  // __HIPCC__

@@ -29,11 +29,17 @@ __global__ __launch_bounds__(256) void field_fwd_kernel(GridDev g, NetLds s, con
         const bool valid = p_raw < M;
         const int64_t p = valid ? p_raw : M - 1;
         const PointIn q = fetch_point(src, p, COLOR);
+        float lat[24];   // this lane's half of the latent row, fetched under the hash-grid gathers
+        if (COLOR) {
+            const float* lrow = latent + q.n * s.lat + h * s.lat_half;
+#pragma unroll
+            for (int t = 0; t < 24; ++t) lat[t] = t < s.lat_half ? lrow[t] : 0.f;
+        }
 
         // ---- sigma layer 1: encode a level, feed its F features as the next F k-steps ----
         f32x16 a0 = zero16(), a1 = zero16();
-        const float* w1r0 = lds + s.w_s1 + l31 * s.p_s1 + h * g.LH * F;
-        const float* w1r1 = w1r0 + 32 * s.p_s1;
+        const float* w1r0 = lds + kWS1 + l31 * kPS1 + h * g.LH * F;
+        const float* w1r1 = w1r0 + 32 * kPS1;
         for (int j = 0; j < g.LH; ++j) {
             const LevelP lp = level_params(g, j, h);
             const Corners c = level_corners(lp, q.x, q.y, q.z);
@@ -54,54 +60,24 @@ __global__ __launch_bounds__(256) void field_fwd_kernel(GridDev g, NetLds s, con
         a0 = relu16(a0);
         a1 = relu16(a1);
         // ---- sigma layer 2: 64 -> 16 rows (row 0 = sigma, rows 1..15 = geo features) ----
-        const f32x16 o2 = layer_64xN(lds + s.w_s2, s.p_s2, kGeoRows, l31, h, a0, a1);
+        const f32x16 o2 = layer_64xN<kPS2>(lds + kWS2, kGeoRows, l31, h, a0, a1);
         if (valid && h == 0) sigma_out[p] = fmaxf(o2[0], 0.f);
         if (!COLOR) continue;
 
         // ---- colour layer 1: inputs [geo(15) | SH | latent], K split between the halves ----
-        f32x16 c0 = zero16(), c1 = zero16();
-        const float* wc0 = lds + s.w_c1 + l31 * s.p_c1;
-        const float* wc1 = wc0 + 32 * s.p_c1;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {  // geo: register t holds sigma-net row krow(t) + 4h
-            const int row = krow(t) + 4 * h;
-            const bool is_sigma = row == 0;
-            const int in = is_sigma ? 0 : row - 1;
-            const float b = is_sigma ? 0.f : o2[t];
-            c0 = MFMA32(wc0[in], b, c0);
-            c1 = MFMA32(wc1[in], b, c1);
-        }
-        if (s.sh_dim > 0) {
+        f32x16 c0, c1;
+        {
             float sh[16];
             sh16(q.dx, q.dy, q.dz, sh);
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                if (t < s.sh_half) {
-                    float b = h ? sh[8 + t] : sh[t];
-                    if (s.sh_half == 2) b = h ? sh[2 + t] : sh[t];
-                    const int in = 15 + h * s.sh_half + t;
-                    c0 = MFMA32(wc0[in], b, c0);
-                    c1 = MFMA32(wc1[in], b, c1);
-                }
-            }
-        }
-        {
-            const float* lrow = latent + q.n * s.lat + h * s.lat_half;
-            const int base = 15 + s.sh_dim + h * s.lat_half;
-#pragma unroll 4
-            for (int t = 0; t < s.lat_half; ++t) {
-                const float b = lrow[t];
-                c0 = MFMA32(wc0[base + t], b, c0);
-                c1 = MFMA32(wc1[base + t], b, c1);
-            }
+            color_layer1(lds, s, l31, h, o2, sh, lat, c0, c1);
         }
         c0 = relu16(c0);
         c1 = relu16(c1);
         f32x16 e0, e1;
-        layer_64x64(lds + s.w_c2, s.p_c2, l31, h, c0, c1, e0, e1);
+        layer_64x64<kPC2>(lds + kWC2, l31, h, c0, c1, e0, e1);
         e0 = relu16(e0);
         e1 = relu16(e1);
-        const f32x16 o3 = layer_64xN(lds + s.w_c3, s.p_c3, 3, l31, h, e0, e1);
+        const f32x16 o3 = layer_64xN<kPC3>(lds + kWC3, 3, l31, h, e0, e1);
         if (valid && h == 0) {
             rgb_out[p * 3 + 0] = 1.f / (1.f + expf(-o3[0]));
             rgb_out[p * 3 + 1] = 1.f / (1.f + expf(-o3[1]));
