@@ -91,7 +91,8 @@ def train_step(model, renderer, loader, opt, n_rays, it, world):
     loss, _ = helpers.fused_train_loss(rgb, rgb_gt, weights, zs, lam_dist, 1e-1)
     loss.backward()
     if world > 1:
-        parallel.all_reduce_grads([p for g in opt.param_groups for p in g['params']])
+        skip = [opt._table_param] if opt.table_reduced_by_pipeline() else []
+        parallel.all_reduce_grads([p for g in opt.param_groups for p in g['params']], skip=skip)
         opt.grad_scale = 1.0 / world
     opt.step()
     return loss
@@ -178,7 +179,9 @@ def main():
     for name, (launches, total_ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
         per_step_ms = total_ms / args.profile_steps
         if name == 'nerf_adam_step':
-            bytes_step = 32 * n_params
+            bytes_step = 32 * n_params                       # all slices / tensors of one step together
+        elif name == 'nerf_hashgrid_scatter':
+            bytes_step = algorithmic_bytes(name, args.rays, n_params)   # the per-level launches of one step together
         else:
             b = algorithmic_bytes(name, args.rays, n_params)
             bytes_step = b * (launches / args.profile_steps) if b else None

@@ -129,9 +129,11 @@ int nerf_field_bwd(const NerfGridCfg* grid, const NerfNetCfg* net, const float* 
                    float* dlatent, void* stream);
 
 /* The table-scatter half of nerf_field_bwd on its own: dtable += scatter(dfeat) for the points of `src`
- * (the same trilinear weights as the forward gather; what tcnn's HashGrid backward does). */
+ * (the same trilinear weights as the forward gather; what tcnn's HashGrid backward does), restricted to
+ * levels [level_begin, level_begin + level_count) so that a caller can pipeline per-level
+ * scatter -> all-reduce -> optimizer step on separate streams. */
 int nerf_hashgrid_scatter(const NerfGridCfg* grid, const NerfPointSrc* src, const float* dfeat /*[M,L*F]*/,
-                          float* dtable, void* stream);
+                          float* dtable, int level_begin, int level_count, void* stream);
 
 /* ---- hierarchical resampling ---- */
 /* renderer.py:154-160: alpha = 1-exp(-sigma*delta), exclusive transmittance, weights. zlog has

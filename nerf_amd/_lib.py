@@ -51,7 +51,7 @@ SIGNATURES = {
     'nerf_density_fwd': (_I, [_G, _N, _P, _P, _S, _P, _P, _P]),
     'nerf_field_fwd': (_I, [_G, _N, _P, _P, _P, _P, _I64, _S, _P, _P, _P, _P, _P]),
     'nerf_field_bwd': (_I, [_G, _N, _P, _P, _P, _P, _I64, _S, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    'nerf_hashgrid_scatter': (_I, [_G, _S, _P, _P, _P]),
+    'nerf_hashgrid_scatter': (_I, [_G, _S, _P, _P, _I, _I, _P]),
     'nerf_coarse_weights': (_I, [_P, _P, _I64, _I64, _I, _P, _P]),
     'nerf_reweight': (_I, [_P, _I64, _I, _F, C.POINTER(C.c_int32), _I, _P, _P]),
     'nerf_sample_pdf': (_I, [_P, _I64, _P, _P, _P, _I64, _I, _I, _P, _P, _P, _P]),

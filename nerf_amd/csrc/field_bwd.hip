@@ -381,5 +381,5 @@ extern "C" int nerf_field_bwd(const NerfGridCfg* grid, const NerfNetCfg* net, co
 #undef LAUNCH2
     rc = nerf_launch_status("nerf_field_bwd");
     if (rc || !dtable) return rc;
-    return nerf_hashgrid_scatter(grid, src, dfeat, dtable, stream);
+    return nerf_hashgrid_scatter(grid, src, dfeat, dtable, 0, grid->n_levels, stream);
 }

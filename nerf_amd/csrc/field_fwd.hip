@@ -118,8 +118,8 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(GridDev g, const floa
 template <int F>
 __global__ __launch_bounds__(256) void scatter_kernel(GridDev g, NerfPointSrc src, const float* __restrict__ x01,
                                                       const float* __restrict__ dfeat, int64_t M,
-                                                      float* __restrict__ dtable) {
-    const int l = blockIdx.y;
+                                                      float* __restrict__ dtable, int level0) {
+    const int l = level0 + blockIdx.y;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t p = t / (8 * F);
     if (p >= M) return;
@@ -287,17 +287,17 @@ int nerf_hashgrid_fwd(const NerfGridCfg* grid, const float* table, const float* 
 }
 
 static int launch_scatter(const NerfGridCfg* grid, const NerfPointSrc* src, const float* x01, const float* dfeat,
-                          int64_t n_points, float* dtable, void* stream) {
+                          int64_t n_points, float* dtable, int level0, int n_levels, void* stream) {
     const GridDev g = make_grid_dev(grid);
     NerfPointSrc s = {};
     if (src) s = *src;
     hipStream_t st = (hipStream_t)stream;
     const int F = grid->n_features;
-    const dim3 nb((unsigned)ceil_div64(n_points * 8 * F, 256), (unsigned)g.L);
+    const dim3 nb((unsigned)ceil_div64(n_points * 8 * F, 256), (unsigned)n_levels);
     switch (F) {
-        case 1: scatter_kernel<1><<<nb, 256, 0, st>>>(g, s, x01, dfeat, n_points, dtable); break;
-        case 2: scatter_kernel<2><<<nb, 256, 0, st>>>(g, s, x01, dfeat, n_points, dtable); break;
-        case 4: scatter_kernel<4><<<nb, 256, 0, st>>>(g, s, x01, dfeat, n_points, dtable); break;
+        case 1: scatter_kernel<1><<<nb, 256, 0, st>>>(g, s, x01, dfeat, n_points, dtable, level0); break;
+        case 2: scatter_kernel<2><<<nb, 256, 0, st>>>(g, s, x01, dfeat, n_points, dtable, level0); break;
+        case 4: scatter_kernel<4><<<nb, 256, 0, st>>>(g, s, x01, dfeat, n_points, dtable, level0); break;
         default: nerf_set_error("scatter: unsupported n_features"); return NERF_EUNSUPPORTED;
     }
     return nerf_launch_status("nerf_hashgrid_bwd");
@@ -308,7 +308,7 @@ int nerf_hashgrid_bwd(const NerfGridCfg* grid, const float* x01, const float* do
     NERF_REQUIRE(grid && x01 && dout && dtable, "null pointer");
     NERF_REQUIRE(n_points >= 0 && grid->total_entries < (1ull << 32), "bad sizes");
     if (n_points == 0) return 0;
-    return launch_scatter(grid, nullptr, x01, dout, n_points, dtable, stream);
+    return launch_scatter(grid, nullptr, x01, dout, n_points, dtable, 0, grid->n_levels, stream);
 }
 
 int nerf_sh_fwd(const float* d01, int64_t n_points, int degree, float* out, void* stream) {
@@ -334,11 +334,12 @@ int nerf_mlp_fwd(const float* params, const int32_t* dims, int n_layers, const f
 }  // extern "C"
 
 extern "C" int nerf_hashgrid_scatter(const NerfGridCfg* grid, const NerfPointSrc* src, const float* dfeat, float* dtable,
-                                     void* stream) {
+                                     int level_begin, int level_count, void* stream) {
     NERF_REQUIRE(grid && dfeat && dtable, "null pointer");
     NERF_REQUIRE(grid->total_entries < (1ull << 32), "bad grid");
     int rc = nerf_check_src("nerf_hashgrid_scatter", src, false);
     if (rc) return rc;
-    if (src->n_points == 0) return 0;
-    return launch_scatter(grid, src, nullptr, dfeat, src->n_points, dtable, stream);
+    NERF_REQUIRE(level_begin >= 0 && level_count >= 0 && level_begin + level_count <= grid->n_levels, "bad level range");
+    if (src->n_points == 0 || level_count == 0) return 0;
+    return launch_scatter(grid, src, nullptr, dfeat, src->n_points, dtable, level_begin, level_count, stream);
 }

@@ -168,8 +168,7 @@ class _FieldFn(torch.autograd.Function):
         check(lib().nerf_field_bwd(C.byref(net.encoder.cfg), C.byref(net.net_cfg), ptr(table), ptr(sigma_w), ptr(color_w),
                                    ptr(latent), net.N, C.byref(src), ptr(xh), ptr(f32(dsigma)), ptr(f32(drgb)),
                                    ptr(dfeat), None, ptr(dsw), ptr(dcw), ptr(dlat), stream()), 'nerf_field_bwd')
-        check(lib().nerf_hashgrid_scatter(C.byref(net.encoder.cfg), C.byref(src), ptr(dfeat), ptr(dtable), stream()),
-              'nerf_hashgrid_scatter')
+        net.scatter_table(src, dfeat, dtable)
         if direct:
             return None, None, None, None, None, None, None
         return dtable, dsw, dcw, dlat, None, None, None
@@ -217,6 +216,7 @@ class NeRFNetwork(nn.Module):
         self.net_cfg = NerfNetCfg(sigma_hidden_dim, sigma_num_layers, geo_feat_dim, color_num_layers, encoding_dir_degree,
                                   latent_embedding_dim)
         self.direct_grads = False
+        self.table_pipeline = None
 
     # ---- gradient plumbing --------------------------------------------------------------
     def enable_direct_grads(self, on=True):
@@ -227,6 +227,22 @@ class NeRFNetwork(nn.Module):
                 if p is not None and p.grad is None:
                     p.grad = torch.zeros_like(p)
         self.direct_grads = bool(on)
+
+    def scatter_table(self, src, dfeat, dtable):
+        """dtable += scatter(dfeat).  With a table pipeline attached (FusedAdam.attach) the scatter is issued
+        level by level, big hashed levels first, with an event after each level so that the optimizer (and,
+        under data parallelism, the gradient all-reduce) of a level can start while later levels still scatter."""
+        cfg = self.encoder.cfg
+        pipe = self.table_pipeline
+        if pipe is None:
+            check(lib().nerf_hashgrid_scatter(C.byref(cfg), C.byref(src), ptr(dfeat), ptr(dtable), 0, cfg.n_levels, stream()),
+                  'nerf_hashgrid_scatter')
+            return
+        pipe.begin(dtable)
+        for (l0, cnt) in pipe.groups:
+            check(lib().nerf_hashgrid_scatter(C.byref(cfg), C.byref(src), ptr(dfeat), ptr(dtable), l0, cnt, stream()),
+                  'nerf_hashgrid_scatter')
+            pipe.level_done(l0, cnt)
 
     # ---- reference surface ----------------------------------------------------------------
     def _field(self, src_kwargs, want_xyz=False):

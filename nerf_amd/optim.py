@@ -2,8 +2,50 @@
 reference's optimizer wiring (train.py:84-96: three groups, per-group lr / weight_decay,
 LambdaLR on top) works unchanged.  Update rule = torch.optim.Adam's single-tensor path."""
 import torch
+import torch.distributed as dist
 
 from ._lib import check, lib, ptr, stream
+
+
+class TablePipeline(object):
+    """Per-level pipeline for the hash-table gradient: scatter(level group) on the main stream ->
+    [all-reduce of that slice, when distributed] -> Adam on that slice on a side stream.
+
+    The scatter is bound by the rate of memory-side atomics and the Adam pass by HBM streaming, so the two
+    overlap almost perfectly; without the pipeline they run back to back.  Level groups are ordered with the
+    large hashed levels first so that the tail left after the last scatter is a small dense level."""
+
+    def __init__(self, grid_cfg, n_features):
+        L = grid_cfg.n_levels
+        groups = [(l, 1) for l in range(L) if grid_cfg.hashed[l]]
+        dense = [l for l in range(L) if not grid_cfg.hashed[l]]
+        if dense:   # the dense pyramid is small: one group, last
+            groups.append((dense[0], len(dense)))
+        self.groups = groups
+        self.slices = {}
+        for (l0, cnt) in groups:
+            a = int(grid_cfg.offset[l0]) * n_features
+            b = (int(grid_cfg.offset[l0 + cnt]) if l0 + cnt < L else int(grid_cfg.total_entries)) * n_features
+            self.slices[l0] = (a, b)
+        self.events = {}
+        self.works = {}
+        self.side = None
+        self.pending = False
+        self.dtable = None
+
+    def begin(self, dtable):
+        self.dtable = dtable
+        self.pending = True
+        self.works = {}
+
+    def level_done(self, l0, cnt):
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            a, b = self.slices[l0]
+            self.works[l0] = dist.all_reduce(self.dtable[a:b], op=dist.ReduceOp.SUM, async_op=True)
+        ev = self.events.get(l0)
+        if ev is None:
+            ev = self.events[l0] = torch.cuda.Event()
+        ev.record()
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -11,11 +53,18 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.grad_scale = 1.0
         self._grads_cleared = False
+        self._table_param = None
+        self._pipeline = None
 
-    def attach(self, model):
+    def attach(self, model, pipeline=True):
         """Give every parameter a persistent .grad and let the model's backward kernel accumulate into
-        it directly; the step kernel then clears the gradient in the same pass (zero_grad is free)."""
+        it directly; the step kernel then clears the gradient in the same pass (zero_grad is free).
+        With `pipeline`, the hash-table update runs as a per-level scatter -> (all-reduce) -> Adam pipeline."""
         model.enable_direct_grads(True)
+        self._table_param = model.encoder.params
+        if pipeline:
+            model.table_pipeline = TablePipeline(model.encoder.cfg, model.encoder.cfg.n_features)
+            self._pipeline = model.table_pipeline
         return self
 
     def zero_grad(self, set_to_none=False):
@@ -40,7 +89,35 @@ class FusedAdam(torch.optim.Optimizer):
                     st['exp_avg'] = torch.zeros_like(p)
                     st['exp_avg_sq'] = torch.zeros_like(p)
                 st['step'] += 1
-                check(lib().nerf_adam_step(ptr(p), ptr(p.grad), ptr(st['exp_avg']), ptr(st['exp_avg_sq']), p.numel(),
-                                           group['lr'], b1, b2, group['eps'], group['weight_decay'], st['step'],
-                                           self.grad_scale, 1, stream()), 'nerf_adam_step')
+                pipe = self._pipeline
+                if pipe is not None and p is self._table_param and pipe.pending:
+                    self._pipelined_table_step(p, st, group, b1, b2, pipe)
+                    continue
+                self._adam(p, p.grad, st['exp_avg'], st['exp_avg_sq'], group, b1, b2, st['step'])
         self._grads_cleared = True
+
+    def _adam(self, p, g, m, v, group, b1, b2, step):
+        check(lib().nerf_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), group['lr'], b1, b2, group['eps'],
+                                   group['weight_decay'], step, self.grad_scale, 1, stream()), 'nerf_adam_step')
+
+    def table_reduced_by_pipeline(self):
+        """True when the pending table gradient is being all-reduced level by level by the pipeline
+        (the trainer must then leave the table out of its own gradient all-reduce)."""
+        return self._pipeline is not None and self._pipeline.pending and bool(self._pipeline.works)
+
+    def _pipelined_table_step(self, p, st, group, b1, b2, pipe):
+        main = torch.cuda.current_stream()
+        if pipe.side is None:
+            pipe.side = torch.cuda.Stream()
+        flat_p, flat_g = p.view(-1), p.grad.view(-1)
+        flat_m, flat_v = st['exp_avg'].view(-1), st['exp_avg_sq'].view(-1)
+        with torch.cuda.stream(pipe.side):
+            for (l0, cnt) in pipe.groups:
+                a, b = pipe.slices[l0]
+                pipe.side.wait_event(pipe.events[l0])
+                w = pipe.works.get(l0)
+                if w is not None:
+                    w.wait()                      # side stream waits for the slice's all-reduce
+                self._adam(flat_p[a:b], flat_g[a:b], flat_m[a:b], flat_v[a:b], group, b1, b2, st['step'])
+        main.wait_stream(pipe.side)
+        pipe.pending = False

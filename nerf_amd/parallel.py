@@ -47,13 +47,16 @@ def shard_range(total, rank_, world):
     return start, start + base + (1 if rank_ < rem else 0)
 
 
-def all_reduce_grads(params, async_op=False):
+def all_reduce_grads(params, async_op=False, skip=()):
     """SUM-all-reduce the .grad of every parameter (largest first so the big transfer starts early).
+    `skip`: parameters whose gradient is reduced elsewhere (the pipelined hash table).
     Returns the list of work handles when async_op."""
     if world_size() == 1:
         return []
     handles = []
-    for p in sorted((p for p in params if p is not None and p.grad is not None), key=lambda t: -t.numel()):
+    skip_ids = {id(p) for p in skip}
+    for p in sorted((p for p in params if p is not None and p.grad is not None and id(p) not in skip_ids),
+                    key=lambda t: -t.numel()):
         h = dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=async_op)
         if async_op:
             handles.append(h)

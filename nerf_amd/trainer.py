@@ -89,7 +89,8 @@ class Trainer(object):
             loss.backward()
             world = parallel.world_size()
             if world > 1:
-                parallel.all_reduce_grads([p for g in self.optimizer.param_groups for p in g['params']])
+                skip = [self.optimizer._table_param] if getattr(self.optimizer, 'table_reduced_by_pipeline', lambda: False)() else []
+                parallel.all_reduce_grads([p for g in self.optimizer.param_groups for p in g['params']], skip=skip)
                 if hasattr(self.optimizer, 'grad_scale'):
                     self.optimizer.grad_scale = 1.0 / world
             self.optimizer.step()
