@@ -1,0 +1,76 @@
+"""Dense geometry extraction with the reference's surface (allign/extract_dense_geometry.py:7-101):
+camera-frustum occupancy mask, then bulk field queries over voxel_res^3 voxel centres, keeping the
+points with sigma > thresh.  Differences, on purpose:
+
+* voxel coordinates are generated on the GPU per batch (the reference builds them on the CPU and copies,
+  :73-79) and results stay on the GPU until the end (the reference concatenates on the CPU per batch, :92-95);
+* under torch.distributed each rank takes a contiguous slab of the voxel index range and the
+  variable-length results are all_gathered once;
+* the open3d wrapper ``generate_dense_pointcloud`` is out of scope (open3d is not part of the hot path).
+The field evaluation itself is ``NeRFNetwork.forward`` -> nerf_field_fwd (HIP)."""
+import torch
+
+from . import parallel
+
+
+class ExtractDenseGeometry():
+    def __init__(self, model, dataloader, mask_res, voxel_res, batch_size, thresh, outer_bound):
+        self.model = model
+        self.dataloader = dataloader
+        self.mask_res = mask_res
+        self.voxel_res = voxel_res
+        self.batch_size = batch_size
+        self.thresh = thresh
+        self.outer_bound = outer_bound
+
+    @torch.no_grad()
+    def get_valid_positions(self, N, H, W, K, E, res):
+        """allign/extract_dense_geometry.py:28-55: inside the unit sphere AND seen by at least one camera."""
+        dev = K.device
+        mask_full = torch.zeros((res, res, res), dtype=torch.bool, device=dev)
+        d = torch.linspace(-1, 1, res, device=dev)
+        Rinv = torch.inverse(E[:, None, None, :3, :3])
+        for i in range(res):
+            D = torch.stack(torch.meshgrid(d[i:i + 1], d, d, indexing='ij'), dim=-1)[0]
+            inside = torch.linalg.norm(D, dim=-1) < 1
+            rel = D[None] - E[:, None, None, :3, -1]
+            cam = Rinv @ rel[..., None]
+            pix_ = K[:, None, None, ...] @ cam
+            pix = pix_ / pix_[:, :, :, 2, None, :]
+            seen = ((pix[..., 0, 0] > 0) & (pix[..., 0, 0] < H) & (pix[..., 1, 0] > 0) & (pix[..., 1, 0] < W)
+                    & (pix_[..., 2, 0] > 0))
+            mask_full[i] = inside & seen.any(dim=0)
+        return mask_full
+
+    @torch.no_grad()
+    def extract_dense_geometry(self, N, H, W, K, E, mask=None):
+        """allign/extract_dense_geometry.py:58-101.  Returns (points [P,3], colors [P,3]) on the CPU."""
+        if mask is None:
+            mask = self.get_valid_positions(N, H, W, K, E, res=self.mask_res)
+        dev = mask.device
+        R = self.voxel_res
+        voxels = torch.linspace(-1 + 1 / R, 1 - 1 / R, R).to(dev)     # built on the CPU like the reference, then moved
+        num_samples = R ** 3
+        start, stop = parallel.shard_range(num_samples, parallel.rank(), parallel.world_size())
+        points, colors = [], []
+        dir_z = torch.tensor([0.0, 0.0, 1.0], device=dev)
+        for a in range(start, stop, self.batch_size):
+            b = min(stop, a + self.batch_size)
+            n = torch.arange(a, b, device=dev)
+            x = voxels[torch.div(n, R ** 2, rounding_mode='floor')]
+            y = voxels[torch.div(n, R, rounding_mode='floor') % R]
+            z = voxels[n % R]
+            keep = mask[((x + 1) / 2 * mask.shape[0]).to(torch.int64), ((y + 1) / 2 * mask.shape[1]).to(torch.int64),
+                        ((z + 1) / 2 * mask.shape[2]).to(torch.int64)]
+            xyz = torch.stack((x, y, z), dim=-1)[keep].contiguous()
+            if xyz.shape[0] > 0:
+                dirs = dir_z[None].expand(xyz.shape[0], 3).contiguous()
+                n_i = torch.zeros(xyz.shape[0], dtype=torch.int64, device=dev)
+                sigmas, rgbs, _ = self.model(xyz, dirs, n_i, self.outer_bound)
+                sel = sigmas > self.thresh
+                points.append(xyz[sel])
+                colors.append(rgbs[sel])
+        cat = lambda xs: torch.cat(xs, dim=0) if xs else torch.zeros((0, 3), device=dev)
+        pts = parallel.gather_varlen(cat(points))
+        col = parallel.gather_varlen(cat(colors))
+        return pts.cpu(), col.cpu()

@@ -1,0 +1,131 @@
+"""Multi-process logic on CPU (gloo, world_size 2): the data-parallel gradient path, the
+inference slice gather and the variable-length extraction gather.  The gradient PRODUCER here is
+the CPU oracle (tests may use it); what is under test is nerf_amd.parallel."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _init(rank, world, port):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+
+
+def _batch(N, seed):
+    from nerf_amd.loaders.procedural import sphere_cameras
+    K_all, E_all = sphere_cameras(5, 0)
+    g = torch.Generator().manual_seed(seed)
+    n = torch.randint(0, 5, (N,), generator=g)
+    h = torch.randint(0, 800, (N,), generator=g)
+    w = torch.randint(0, 800, (N,), generator=g)
+    return n, h, w, K_all[n], E_all[n], torch.rand(3, generator=g), torch.rand(N, 128, generator=g), torch.rand(N, 3, generator=g)
+
+
+def _oracle(seed=2):
+    from oracle import ref_cpu
+    kw = dict(encoding_n_levels=4, encoding_log2_hashmap_size=12, latent_embedding_dim=48)
+    net = ref_cpu.OracleNetwork(5, seed=seed, **kw)
+    with torch.no_grad():
+        net.encoder_params.mul_(1e3)
+    return net, ref_cpu.OracleRenderer(net, 2, 2.5, [1.6, 4.8], [64], 128, 0.2)
+
+
+def _grads(net, R, batch):
+    from oracle import ref_cpu
+    n, h, w, K, E, bg, noise, gt = batch
+    net.zero_grad()
+    img, wts, zs, _ = R.render(n, h, w, K, E, bg, noise=noise)
+    loss, _ = ref_cpu.train_loss(img, gt, wts, zs, 3, 100, 1e-5, 1e-2, 1e-1, 1e-1)
+    loss.backward()
+    return [p.grad.clone() for p in net.parameters()]
+
+
+def _dp_worker(rank, world, port, q):
+    from nerf_amd import parallel
+    _init(rank, world, port)
+    net, R = _oracle()
+    full = _batch(32, 7)
+    a, b = parallel.shard_range(32, rank, world)
+    mine = tuple(t[a:b] if (torch.is_tensor(t) and t.dim() > 0 and t.shape[0] == 32) else t for t in full)
+    _grads(net, R, mine)
+    params = list(net.parameters())
+    parallel.all_reduce_grads(params)
+    out = [p.grad / world for p in params]                 # the 1/world factor the fused Adam applies
+    if rank == 0:
+        q.put([o.numpy() for o in out])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_gradients_match_single_process():
+    """mean-over-rays loss: all-reduced (SUM) shard gradients / world == full-batch gradients."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    got = q.get(timeout=300)
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    net, R = _oracle()
+    want = _grads(net, R, _batch(32, 7))
+    for g, w in zip(got, want):
+        scale = float(w.abs().max()) + 1e-12
+        torch.testing.assert_close(torch.from_numpy(g), w, rtol=1e-4, atol=1e-5 * scale)
+
+
+def _gather_worker(rank, world, port, q):
+    from nerf_amd import parallel
+    _init(rank, world, port)
+    total = 11                                             # ragged: 6 + 5
+    full = torch.arange(total * 3, dtype=torch.float32).reshape(total, 3)
+    a, b = parallel.shard_range(total, rank, world)
+    got = parallel.gather_slices(full[a:b].clone(), total)
+    rows = full[full[:, 0] % 2 == rank]                    # different row counts per rank (incl. possibly none)
+    var = parallel.gather_varlen(rows.clone())
+    empty = parallel.gather_varlen(torch.zeros(0, 3) if rank == 1 else full[:2].clone())
+    if rank == 0:
+        q.put((got.numpy(), var.numpy(), empty.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_slice_and_varlen_gathers():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    got, var, empty = q.get(timeout=120)
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    full = torch.arange(33, dtype=torch.float32).reshape(11, 3)
+    assert torch.equal(torch.from_numpy(got), full)
+    want_var = torch.cat([full[full[:, 0] % 2 == 0], full[full[:, 0] % 2 == 1]])
+    assert torch.equal(torch.from_numpy(var), want_var)
+    assert torch.equal(torch.from_numpy(empty), full[:2])
+
+
+def test_shard_range_covers_everything():
+    from nerf_amd.parallel import shard_range
+    for total in (0, 1, 7, 640000, 134217728):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
