@@ -25,10 +25,14 @@ def init_from_env(backend=None):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-        if backend == 'nccl':
+            # NERF_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsals on a 1-GPU box)
+            backend = os.environ.get('NERF_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+        if torch.cuda.is_available():
+            local = local % torch.cuda.device_count()
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if torch.cuda.is_available():
+        local = local % torch.cuda.device_count()
     return rank, world, local
 
 

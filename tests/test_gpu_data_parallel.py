@@ -1,0 +1,93 @@
+"""Data-parallel training on the GPU path: two ranks (gloo, both on cuda:0 -- the test box has one GPU) each
+train on their half of every batch through the per-level scatter -> all-reduce -> Adam pipeline; the result must
+equal one process training on the whole batch (mean-over-rays loss => SUM of shard grads / world)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+KW = dict(encoding_precision='float32', encoding_n_levels=8, encoding_n_features_per_level=2,
+          encoding_log2_hashmap_size=15, geo_feat_dim=15, sigma_hidden_dim=64, sigma_num_layers=2,
+          encoding_dir_precision='float32', encoding_dir_encoding='SphericalHarmonics', encoding_dir_degree=4,
+          latent_embedding_dim=48, color_hidden_dim=64, color_num_layers=3)
+N, STEPS = 128, 3
+
+
+def _batches():
+    from nerf_amd.loaders.procedural import sphere_cameras
+    K_all, E_all = sphere_cameras(5, 0)
+    g = torch.Generator().manual_seed(4)
+    out = []
+    for _ in range(STEPS):
+        n = torch.randint(0, 5, (N,), generator=g)
+        h = torch.randint(0, 800, (N,), generator=g)
+        w = torch.randint(0, 800, (N,), generator=g)
+        out.append((n, h, w, K_all[n], E_all[n], torch.rand(3, generator=g), torch.rand(N, 128, generator=g),
+                    torch.rand(N, 3, generator=g)))
+    return out
+
+
+def _train(rank, world):
+    from nerf_amd import helpers, parallel
+    from nerf_amd.nets import NeRFNetwork
+    from nerf_amd.optim import FusedAdam
+    from nerf_amd.renderer import NerfRenderer
+    net = NeRFNetwork(5, seed=1, **KW)
+    with torch.no_grad():
+        net.encoder.params.mul_(1e3)
+    R = NerfRenderer(net, 2, 2.5, [1.6, 4.8], [64], 128, 0.2)
+    opt = FusedAdam([{'params': list(net.encoder.parameters()) + [net.latent_emb], 'lr': 2e-2},
+                     {'params': list(net.sigma_net.parameters()) + list(net.color_net.parameters()), 'lr': 1e-3,
+                      'weight_decay': 1e-6}], betas=(0.9, 0.99), eps=1e-15).attach(net)
+    for b in _batches():
+        a, e = parallel.shard_range(N, rank, world)
+        n, h, w, K, E, bg, noise, gt = [t[a:e].cuda() if t.dim() > 0 and t.shape[0] == N else t.cuda() for t in b]
+        opt.zero_grad()
+        img, wts, zs, _ = R.render(n, h, w, K, E, bg, noise=noise)
+        loss, _ = helpers.fused_train_loss(img, gt, wts, zs, 1e-3, 1e-1)
+        loss.backward()
+        if world > 1:
+            skip = [opt._table_param] if opt.table_reduced_by_pipeline() else []
+            assert skip, 'the table gradient must be reduced by the pipeline'
+            parallel.all_reduce_grads([p for g in opt.param_groups for p in g['params']], skip=skip)
+            opt.grad_scale = 1.0 / world
+        opt.step()
+    torch.cuda.synchronize()
+    return [p.detach().cpu() for p in (net.encoder.params, net.sigma_net.params, net.color_net.params, net.latent_emb)]
+
+
+def _worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    out = _train(rank, world)
+    if rank == 0:
+        q.put([o.numpy() for o in out])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_training_matches_single_process():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    got = q.get(timeout=150)
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    want = _train(0, 1)
+    for g, w, name in zip(got, want, ('table', 'sigma_net', 'color_net', 'latent')):
+        # Adam divides by sqrt(v): elements whose gradient is ~0 amplify rounding differences between the two
+        # reduction orders, so compare with an absolute bar at the scale of one update step (lr)
+        torch.testing.assert_close(torch.from_numpy(g), w, rtol=0, atol=2e-3, msg=lambda m, n=name: n + ': ' + m)
+        frac = float(((torch.from_numpy(g) - w).abs() > 1e-5).float().mean())
+        assert frac < 0.02, (name, frac)
