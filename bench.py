@@ -66,7 +66,7 @@ def algorithmic_flops(name, n_rays, Sc=64, Sf=SF):
             'nerf_field_bwd': n_rays * Sf * 3 * 25856}.get(name)
 
 
-def build_gpu(device, rank, n_rays):
+def build_gpu(device, rank, n_rays, pipeline=True):
     from nerf_amd.loaders.procedural import ProceduralSceneLoader
     from nerf_amd.nets import NeRFNetwork
     from nerf_amd.optim import FusedAdam
@@ -78,7 +78,7 @@ def build_gpu(device, rank, n_rays):
         {'name': 'encoding', 'params': list(model.encoder.parameters()), 'lr': 2e-2},
         {'name': 'latent_emb', 'params': [model.latent_emb], 'lr': 2e-2},
         {'name': 'net', 'params': list(model.sigma_net.parameters()) + list(model.color_net.parameters()),
-         'weight_decay': 1e-6, 'lr': 1e-3}], betas=(0.9, 0.99), eps=1e-15).attach(model)
+         'weight_decay': 1e-6, 'lr': 1e-3}], betas=(0.9, 0.99), eps=1e-15).attach(model, pipeline=pipeline)
     return model, renderer, loader, opt
 
 
@@ -135,8 +135,14 @@ def main():
     ap.add_argument('--rays', type=int, default=4096, help='rays per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-render', action='store_true')
+    ap.add_argument('--no-pipeline', action='store_true', help='dense table all-reduce + one Adam pass (no per-level pipeline)')
     ap.add_argument('--profile-steps', type=int, default=5)
+    ap.add_argument('--table-log2', type=int, default=24, help='REHEARSAL ONLY: smaller hash table (the metric config is 24)')
+    ap.add_argument('--hang-trace', type=int, default=0, help='dump all Python stacks to stderr every N seconds')
     args = ap.parse_args()
+    if args.hang_trace > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(args.hang_trace, repeat=True)
 
     from nerf_amd import _lib, parallel
     rank, world, local = parallel.init_from_env()
@@ -146,7 +152,8 @@ def main():
     torch.cuda.set_device(device)
     import torch.distributed as dist
 
-    model, renderer, loader, opt = build_gpu(device, rank, args.rays)
+    NET['encoding_log2_hashmap_size'] = args.table_log2
+    model, renderer, loader, opt = build_gpu(device, rank, args.rays, pipeline=not args.no_pipeline)
     n_params = sum(p.numel() for g in opt.param_groups for p in g['params'])
 
     for it in range(args.warmup):
@@ -234,8 +241,8 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'train step (render + backward + dense Adam), %d rays/GPU/step, 64 coarse + 128 fine '
-                                   'samples/ray, config_base network (L20 F2 T24, SH4, latent 48, 64-wide MLPs), '
-                                   'procedural scene 100 poses 800x800' % args.rays,
+                                   'samples/ray, config_base network (L20 F2 T%d, SH4, latent 48, 64-wide MLPs), '
+                                   'procedural scene 100 poses 800x800' % (args.rays, args.table_log2),
                        'rays_per_gpu': args.rays, 'global_rays': args.rays * world, 'parallelism': 'dp%d' % world},
             'roofline': roofline, 'cpu_baseline': cpu, 'render': render, 'kernels': kernels,
         }
