@@ -52,6 +52,11 @@ def algorithmic_bytes(name, n_rays, n_params, Sc=64, Sf=SF, L=20, F=2):
         'nerf_field_fwd': n_rays * Sf * (gather + L * F * 4 + 4 + 12 + 12),
         'nerf_field_bwd': n_rays * Sf * (2 * L * F * 4 + 4 + 12),
         'nerf_hashgrid_scatter': n_rays * Sf * (2 * gather + L * F * 4),
+        # level-sharded table (N > 1): every rank handles L/N levels of N x the points = the same totals
+        'nerf_hashgrid_scatter_levels': n_rays * Sf * (2 * gather + L * F * 4),
+        'nerf_hashgrid_encode_levels': n_rays * (Sc + Sf) * (gather + L * F * 4),
+        'nerf_field_from_features': n_rays * Sf * (L * F * 4 + 4 + 12 + 12),
+        'nerf_density_from_features': n_rays * Sc * (L * F * 4 + 4),
         'nerf_adam_step': None,                  # per-tensor launches: 32 B / parameter, summed below
         'nerf_coarse_to_fine': n_rays * (4 * Sc + 12 * Sf),
         'nerf_composite_fwd': n_rays * (Sf * 32 + 16),
@@ -63,7 +68,8 @@ def algorithmic_bytes(name, n_rays, n_params, Sc=64, Sf=SF, L=20, F=2):
 
 def algorithmic_flops(name, n_rays, Sc=64, Sf=SF):
     return {'nerf_density_fwd': n_rays * Sc * 7168, 'nerf_field_fwd': n_rays * Sf * 25856,
-            'nerf_field_bwd': n_rays * Sf * 3 * 25856}.get(name)
+            'nerf_field_bwd': n_rays * Sf * 3 * 25856, 'nerf_field_from_features': n_rays * Sf * 25856,
+            'nerf_density_from_features': n_rays * Sc * 7168}.get(name)
 
 
 def build_gpu(device, rank, n_rays, pipeline=True):
@@ -155,6 +161,10 @@ def main():
     NET['encoding_log2_hashmap_size'] = args.table_log2
     model, renderer, loader, opt = build_gpu(device, rank, args.rays, pipeline=not args.no_pipeline)
     n_params = sum(p.numel() for g in opt.param_groups for p in g['params'])
+    model_sharded = model.level_sharding
+    if model_sharded is not None:      # this rank's Adam pass only covers the levels it owns
+        owned = sum(b - a for a, b in (model_sharded.level_slice(l) for l in model_sharded.mine))
+        n_params = n_params - model.encoder.params.numel() + owned
 
     for it in range(args.warmup):
         train_step(model, renderer, loader, opt, args.rays, it, world)
@@ -187,7 +197,7 @@ def main():
         per_step_ms = total_ms / args.profile_steps
         if name == 'nerf_adam_step':
             bytes_step = 32 * n_params                       # all slices / tensors of one step together
-        elif name == 'nerf_hashgrid_scatter':
+        elif name in ('nerf_hashgrid_scatter', 'nerf_hashgrid_scatter_levels', 'nerf_hashgrid_encode_levels'):
             bytes_step = algorithmic_bytes(name, args.rays, n_params)   # the per-level launches of one step together
         else:
             b = algorithmic_bytes(name, args.rays, n_params)
@@ -243,7 +253,8 @@ def main():
             'config': {'workload': 'train step (render + backward + dense Adam), %d rays/GPU/step, 64 coarse + 128 fine '
                                    'samples/ray, config_base network (L20 F2 T%d, SH4, latent 48, 64-wide MLPs), '
                                    'procedural scene 100 poses 800x800' % (args.rays, args.table_log2),
-                       'rays_per_gpu': args.rays, 'global_rays': args.rays * world, 'parallelism': 'dp%d' % world},
+                       'rays_per_gpu': args.rays, 'global_rays': args.rays * world, 'parallelism': ('dp%d over rays' % world) + (', hash table sharded by level (feature all-to-all)'
+                                                                    if getattr(model_sharded, 'world', 1) > 1 else '')},
             'roofline': roofline, 'cpu_baseline': cpu, 'render': render, 'kernels': kernels,
         }
         print(json.dumps(out), flush=True)

@@ -79,6 +79,13 @@ typedef struct NerfPointSrc {
     float outer_bound;
 } NerfPointSrc;
 
+/* A subset of hash-grid levels, for the level-sharded (multi-GPU) table: column block i of a
+ * [*, count*F] feature matrix belongs to level level[i]. */
+typedef struct NerfLevelSet {
+    int32_t count;
+    int32_t level[NERF_MAX_LEVELS];
+} NerfLevelSet;
+
 int nerf_abi_version(void);
 const char* nerf_last_error(void);
 
@@ -134,6 +141,27 @@ int nerf_field_bwd(const NerfGridCfg* grid, const NerfNetCfg* net, const float* 
  * scatter -> all-reduce -> optimizer step on separate streams. */
 int nerf_hashgrid_scatter(const NerfGridCfg* grid, const NerfPointSrc* src, const float* dfeat /*[M,L*F]*/,
                           float* dtable, int level_begin, int level_count, void* stream);
+
+/* ---- level-sharded hash table (no counterpart in the single-GPU reference) ----
+ * Under multi-GPU training every rank owns a subset of the hash-grid levels.  The owner evaluates
+ * tcnn.Encoding (nets.py:118,154) for ITS levels on the sample points of all ranks, the per-point feature
+ * rows travel by all-to-all, and the MLP half of nets.py:109-164 runs where the rays live.  These four entry
+ * points are the two halves of nerf_density_fwd / nerf_field_fwd / nerf_hashgrid_scatter cut at the feature
+ * matrix. */
+/* out[p*out_stride + i*F + f] = feature f of level levels->level[i] at point p of `src` (either mode). */
+int nerf_hashgrid_encode_levels(const NerfGridCfg* grid, const float* table, const NerfPointSrc* src,
+                                const NerfLevelSet* levels, float* out, int64_t out_stride, void* stream);
+/* dtable += scatter of dfeat[p*dfeat_stride + i*F + f] into level levels->level[i], points of `src`. */
+int nerf_hashgrid_scatter_levels(const NerfGridCfg* grid, const NerfPointSrc* src, const NerfLevelSet* levels,
+                                 const float* dfeat, int64_t dfeat_stride, float* dtable, void* stream);
+/* nets.py:155-161 from ready features: sigma = relu(sigma_net(x_hashtable)[:, 0]). */
+int nerf_density_from_features(const NerfGridCfg* grid, const NerfNetCfg* net, const float* sigma_params,
+                               const float* x_hashtable /*[M,L*F]*/, int64_t n_points, float* sigma, void* stream);
+/* nets.py:120-146 from ready features; `src` still provides directions, image indices and xyz. */
+int nerf_field_from_features(const NerfGridCfg* grid, const NerfNetCfg* net, const float* sigma_params,
+                             const float* color_params, const float* latent_emb, int64_t n_images,
+                             const NerfPointSrc* src, const float* x_hashtable /*[M,L*F]*/, float* sigma, float* rgb,
+                             float* xyz /*nullable*/, void* stream);
 
 /* ---- hierarchical resampling ---- */
 /* renderer.py:154-160: alpha = 1-exp(-sigma*delta), exclusive transmittance, weights. zlog has

@@ -31,8 +31,13 @@ class NerfPointSrc(C.Structure):
                 ('z', C.c_void_p), ('z_stride', C.c_int64), ('inner_bound', C.c_float), ('outer_bound', C.c_float)]
 
 
+class NerfLevelSet(C.Structure):
+    _fields_ = [('count', C.c_int32), ('level', C.c_int32 * NERF_MAX_LEVELS)]
+
+
 _P, _I64, _I, _F = C.c_void_p, C.c_int64, C.c_int, C.c_float
 _G, _N, _S = C.POINTER(NerfGridCfg), C.POINTER(NerfNetCfg), C.POINTER(NerfPointSrc)
+_LS = C.POINTER(NerfLevelSet)
 
 # every symbol include/nerf_hip.h declares, with its argument types
 SIGNATURES = {
@@ -52,6 +57,10 @@ SIGNATURES = {
     'nerf_field_fwd': (_I, [_G, _N, _P, _P, _P, _P, _I64, _S, _P, _P, _P, _P, _P]),
     'nerf_field_bwd': (_I, [_G, _N, _P, _P, _P, _P, _I64, _S, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'nerf_hashgrid_scatter': (_I, [_G, _S, _P, _P, _I, _I, _P]),
+    'nerf_hashgrid_encode_levels': (_I, [_G, _P, _S, _LS, _P, _I64, _P]),
+    'nerf_hashgrid_scatter_levels': (_I, [_G, _S, _LS, _P, _I64, _P, _P]),
+    'nerf_density_from_features': (_I, [_G, _N, _P, _P, _I64, _P, _P]),
+    'nerf_field_from_features': (_I, [_G, _N, _P, _P, _P, _I64, _S, _P, _P, _P, _P, _P]),
     'nerf_coarse_weights': (_I, [_P, _P, _I64, _I64, _I, _P, _P]),
     'nerf_reweight': (_I, [_P, _I64, _I, _F, C.POINTER(C.c_int32), _I, _P, _P]),
     'nerf_sample_pdf': (_I, [_P, _I64, _P, _P, _P, _I64, _I, _I, _P, _P, _P, _P]),

@@ -7,13 +7,16 @@
 namespace {
 
 // One wavefront = 32 points x 2 lane halves; lane half h gathers levels [h*LH, h*LH + LH).
-template <int F, bool COLOR>
+// FEATS: the hash-grid features come ready-made from xh_in (level-sharded table: the level owners encoded
+// them and an all-to-all brought them here) instead of being gathered from `table`.
+template <int F, bool COLOR, bool FEATS>
 __global__ __launch_bounds__(256) void field_fwd_kernel(GridDev g, NetLds s, const float* __restrict__ table,
                                                         const float* __restrict__ sigma_w,
                                                         const float* __restrict__ color_w,
                                                         const float* __restrict__ latent, NerfPointSrc src,
                                                         float* __restrict__ sigma_out, float* __restrict__ rgb_out,
-                                                        float* __restrict__ xh_out, float* __restrict__ xyz_out) {
+                                                        float* __restrict__ xh_out, float* __restrict__ xyz_out,
+                                                        const float* __restrict__ xh_in) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     lds_load_net(lds, s, sigma_w, color_w, COLOR);
 
@@ -28,7 +31,8 @@ __global__ __launch_bounds__(256) void field_fwd_kernel(GridDev g, NetLds s, con
         const int64_t p_raw = tile * kTilePts + l31;
         const bool valid = p_raw < M;
         const int64_t p = valid ? p_raw : M - 1;
-        const PointIn q = fetch_point(src, p, COLOR);
+        PointIn q = {};
+        if (!FEATS || COLOR) q = fetch_point(src, p, COLOR);
         float lat[24];   // this lane's half of the latent row, fetched under the hash-grid gathers
         if (COLOR) {
             const float* lrow = latent + q.n * s.lat + h * s.lat_half;
@@ -42,16 +46,22 @@ __global__ __launch_bounds__(256) void field_fwd_kernel(GridDev g, NetLds s, con
         const float* w1r1 = w1r0 + 32 * kPS1;
         for (int j = 0; j < g.LH; ++j) {
             const LevelP lp = level_params(g, j, h);
-            const Corners c = level_corners(lp, q.x, q.y, q.z);
             float feat[F];
-            gather_level<F>(table, c, feat);
+            if (FEATS) {
+                const float* fsrc = xh_in + p * LF + (lp.active ? h * g.LH + j : 0) * F;
+#pragma unroll
+                for (int f = 0; f < F; ++f) feat[f] = fsrc[f];
+            } else {
+                const Corners c = level_corners(lp, q.x, q.y, q.z);
+                gather_level<F>(table, c, feat);
+            }
 #pragma unroll
             for (int f = 0; f < F; ++f) {
                 const float b = lp.active ? feat[f] : 0.f;
                 a0 = MFMA32(w1r0[j * F + f], b, a0);
                 a1 = MFMA32(w1r1[j * F + f], b, a1);
             }
-            if (xh_out && valid && lp.active) {
+            if (!FEATS && xh_out && valid && lp.active) {
                 float* dst = xh_out + p * LF + (h * g.LH + j) * F;
 #pragma unroll
                 for (int f = 0; f < F; ++f) dst[f] = feat[f];
@@ -109,17 +119,37 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(GridDev g, const floa
     for (int f = 0; f < F; ++f) out[i * F + f] = feat[f];
 }
 
+// Encoding of a level subset for any point source: one thread per (point, level slot).
+template <int F>
+__global__ __launch_bounds__(256) void encode_levels_kernel(GridDev g, const float* __restrict__ table, NerfPointSrc src,
+                                                            NerfLevelSet set, float* __restrict__ out, int64_t stride) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= src.n_points * set.count) return;
+    const int64_t p = i / set.count;
+    const int slot = (int)(i - p * set.count);
+    const int l = set.level[slot];
+    const PointIn q = fetch_point(src, p, false);
+    LevelP lp = {g.scale[l], g.res[l], g.entries[l], g.hashed[l], g.offset[l], true};
+    const Corners c = level_corners(lp, q.x, q.y, q.z);
+    float feat[F];
+    gather_level<F>(table, c, feat);
+#pragma unroll
+    for (int f = 0; f < F; ++f) out[p * stride + slot * F + f] = feat[f];
+}
+
 // Hash-table gradient scatter.  fp32 atomics execute at the memory side at a fixed rate of 64-byte
 // requests (~20 G/s chip-wide), so the cost is the number of distinct 64-B lines per wave
 // instruction.  Lanes are therefore laid out as (point, corner, feature): the 16 lanes of one
 // (point, level) touch ~4-5 lines (corner pairs along x and the F features of an entry share a
 // line) instead of one line per lane -- measured 3.4x faster than one thread per (point, level).
 // grid.y = level, so the level parameters are scalar.
+// Level slot blockIdx.y handles level set.level[y]; its F gradient columns sit at dfeat[p*stride + col0 + y*F].
 template <int F>
 __global__ __launch_bounds__(256) void scatter_kernel(GridDev g, NerfPointSrc src, const float* __restrict__ x01,
                                                       const float* __restrict__ dfeat, int64_t M,
-                                                      float* __restrict__ dtable, int level0) {
-    const int l = level0 + blockIdx.y;
+                                                      float* __restrict__ dtable, NerfLevelSet set, int64_t stride,
+                                                      int col0) {
+    const int l = set.level[blockIdx.y];
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t p = t / (8 * F);
     if (p >= M) return;
@@ -137,7 +167,7 @@ __global__ __launch_bounds__(256) void scatter_kernel(GridDev g, NerfPointSrc sr
     uint32_t idx;
     if (g.hashed[l]) idx = (cx ^ (cy * 2654435761u) ^ (cz * 805459861u)) & (entries - 1u);
     else { idx = cx + cy * res + cz * (res * res); if (idx >= entries) idx %= entries; }
-    atomicAdd(dtable + ((size_t)g.offset[l] + idx) * F + f, w * dfeat[p * (g.L * F) + l * F + f]);
+    atomicAdd(dtable + ((size_t)g.offset[l] + idx) * F + f, w * dfeat[p * stride + col0 + (int)blockIdx.y * F + f]);
 }
 
 __global__ void sh_fwd_kernel(const float* __restrict__ d01, int64_t M, int dim, float* __restrict__ out) {
@@ -218,10 +248,10 @@ static unsigned fwd_grid(int64_t n_points, int lds_bytes) {
     return (unsigned)(want < cap ? want : cap);
 }
 
-template <bool COLOR>
+template <bool COLOR, bool FEATS>
 static int launch_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const float* table, const float* sw, const float* cw,
                       const float* latent, const NerfPointSrc* src, float* sigma, float* rgb, float* xh, float* xyz,
-                      void* stream) {
+                      const float* xh_in, void* stream) {
     const GridDev g = make_grid_dev(grid);
     const NetLds s = make_net_lds(grid, net, COLOR);
     const int lds_bytes = s.total * (int)sizeof(float);
@@ -229,10 +259,10 @@ static int launch_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const floa
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(FF)                                                                                                     \
     do {                                                                                                               \
-        auto kern = field_fwd_kernel<FF, COLOR>;                                                                       \
+        auto kern = field_fwd_kernel<FF, COLOR, FEATS>;                                                                     \
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);  \
         if (e != hipSuccess) { nerf_set_error("field_fwd: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }  \
-        kern<<<nb, 256, lds_bytes, st>>>(g, s, table, sw, cw, latent, *src, sigma, rgb, xh, xyz);                      \
+        kern<<<nb, 256, lds_bytes, st>>>(g, s, table, sw, cw, latent, *src, sigma, rgb, xh, xyz, xh_in);               \
     } while (0)
     switch (grid->n_features) {
         case 1: LAUNCH(1); break;
@@ -253,7 +283,8 @@ int nerf_density_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const float
     if (rc) return rc;
     NERF_REQUIRE(table && sigma_params && sigma, "null pointer");
     if (src->n_points == 0) return 0;
-    return launch_fwd<false>(grid, net, table, sigma_params, nullptr, nullptr, src, sigma, nullptr, x_hashtable, nullptr, stream);
+    return launch_fwd<false, false>(grid, net, table, sigma_params, nullptr, nullptr, src, sigma, nullptr, x_hashtable, nullptr,
+                                    nullptr, stream);
 }
 
 int nerf_field_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const float* table, const float* sigma_params,
@@ -266,7 +297,8 @@ int nerf_field_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const float* 
     NERF_REQUIRE(table && sigma_params && color_params && sigma && rgb, "null pointer");
     NERF_REQUIRE(net->latent_dim == 0 || (latent_emb && n_images > 0), "latent embedding missing");
     if (src->n_points == 0) return 0;
-    return launch_fwd<true>(grid, net, table, sigma_params, color_params, latent_emb, src, sigma, rgb, x_hashtable, xyz, stream);
+    return launch_fwd<true, false>(grid, net, table, sigma_params, color_params, latent_emb, src, sigma, rgb, x_hashtable, xyz,
+                                   nullptr, stream);
 }
 
 int nerf_hashgrid_fwd(const NerfGridCfg* grid, const float* table, const float* x01, int64_t n_points, float* out,
@@ -286,18 +318,33 @@ int nerf_hashgrid_fwd(const NerfGridCfg* grid, const float* table, const float* 
     return nerf_launch_status("nerf_hashgrid_fwd");
 }
 
+static NerfLevelSet level_range(int begin, int count) {
+    NerfLevelSet set = {};
+    set.count = count;
+    for (int i = 0; i < count; ++i) set.level[i] = begin + i;
+    return set;
+}
+
+static int check_level_set(const char* fn, const NerfGridCfg* grid, const NerfLevelSet* set) {
+    if (!set || set->count < 0 || set->count > grid->n_levels) { nerf_set_error("%s: bad level set", fn); return NERF_EINVAL; }
+    for (int i = 0; i < set->count; ++i)
+        if (set->level[i] < 0 || set->level[i] >= grid->n_levels) { nerf_set_error("%s: level out of range", fn); return NERF_EINVAL; }
+    return 0;
+}
+
 static int launch_scatter(const NerfGridCfg* grid, const NerfPointSrc* src, const float* x01, const float* dfeat,
-                          int64_t n_points, float* dtable, int level0, int n_levels, void* stream) {
+                          int64_t n_points, float* dtable, const NerfLevelSet& set, int64_t stride, int col0, void* stream) {
     const GridDev g = make_grid_dev(grid);
+    const int n_levels = set.count;
     NerfPointSrc s = {};
     if (src) s = *src;
     hipStream_t st = (hipStream_t)stream;
     const int F = grid->n_features;
     const dim3 nb((unsigned)ceil_div64(n_points * 8 * F, 256), (unsigned)n_levels);
     switch (F) {
-        case 1: scatter_kernel<1><<<nb, 256, 0, st>>>(g, s, x01, dfeat, n_points, dtable, level0); break;
-        case 2: scatter_kernel<2><<<nb, 256, 0, st>>>(g, s, x01, dfeat, n_points, dtable, level0); break;
-        case 4: scatter_kernel<4><<<nb, 256, 0, st>>>(g, s, x01, dfeat, n_points, dtable, level0); break;
+        case 1: scatter_kernel<1><<<nb, 256, 0, st>>>(g, s, x01, dfeat, n_points, dtable, set, stride, col0); break;
+        case 2: scatter_kernel<2><<<nb, 256, 0, st>>>(g, s, x01, dfeat, n_points, dtable, set, stride, col0); break;
+        case 4: scatter_kernel<4><<<nb, 256, 0, st>>>(g, s, x01, dfeat, n_points, dtable, set, stride, col0); break;
         default: nerf_set_error("scatter: unsupported n_features"); return NERF_EUNSUPPORTED;
     }
     return nerf_launch_status("nerf_hashgrid_bwd");
@@ -308,7 +355,8 @@ int nerf_hashgrid_bwd(const NerfGridCfg* grid, const float* x01, const float* do
     NERF_REQUIRE(grid && x01 && dout && dtable, "null pointer");
     NERF_REQUIRE(n_points >= 0 && grid->total_entries < (1ull << 32), "bad sizes");
     if (n_points == 0) return 0;
-    return launch_scatter(grid, nullptr, x01, dout, n_points, dtable, 0, grid->n_levels, stream);
+    return launch_scatter(grid, nullptr, x01, dout, n_points, dtable, level_range(0, grid->n_levels),
+                          (int64_t)grid->n_levels * grid->n_features, 0, stream);
 }
 
 int nerf_sh_fwd(const float* d01, int64_t n_points, int degree, float* out, void* stream) {
@@ -341,5 +389,70 @@ extern "C" int nerf_hashgrid_scatter(const NerfGridCfg* grid, const NerfPointSrc
     if (rc) return rc;
     NERF_REQUIRE(level_begin >= 0 && level_count >= 0 && level_begin + level_count <= grid->n_levels, "bad level range");
     if (src->n_points == 0 || level_count == 0) return 0;
-    return launch_scatter(grid, src, nullptr, dfeat, src->n_points, dtable, level_begin, level_count, stream);
+    return launch_scatter(grid, src, nullptr, dfeat, src->n_points, dtable, level_range(level_begin, level_count),
+                          (int64_t)grid->n_levels * grid->n_features, level_begin * grid->n_features, stream);
+}
+
+// ---- level-sharded table: the two halves of the fused calls, cut at the feature matrix ----
+extern "C" int nerf_hashgrid_encode_levels(const NerfGridCfg* grid, const float* table, const NerfPointSrc* src,
+                                           const NerfLevelSet* levels, float* out, int64_t out_stride, void* stream) {
+    NERF_REQUIRE(grid && table && out, "null pointer");
+    NERF_REQUIRE(grid->total_entries < (1ull << 32), "bad grid");
+    int rc = nerf_check_src("nerf_hashgrid_encode_levels", src, false);
+    if (rc) return rc;
+    rc = check_level_set("nerf_hashgrid_encode_levels", grid, levels);
+    if (rc) return rc;
+    NERF_REQUIRE(out_stride >= (int64_t)levels->count * grid->n_features, "out_stride smaller than count*F");
+    if (src->n_points == 0 || levels->count == 0) return 0;
+    const GridDev g = make_grid_dev(grid);
+    const unsigned nb = (unsigned)ceil_div64(src->n_points * levels->count, 256);
+    hipStream_t st = (hipStream_t)stream;
+    switch (grid->n_features) {
+        case 1: encode_levels_kernel<1><<<nb, 256, 0, st>>>(g, table, *src, *levels, out, out_stride); break;
+        case 2: encode_levels_kernel<2><<<nb, 256, 0, st>>>(g, table, *src, *levels, out, out_stride); break;
+        case 4: encode_levels_kernel<4><<<nb, 256, 0, st>>>(g, table, *src, *levels, out, out_stride); break;
+        default: nerf_set_error("nerf_hashgrid_encode_levels: unsupported n_features"); return NERF_EUNSUPPORTED;
+    }
+    return nerf_launch_status("nerf_hashgrid_encode_levels");
+}
+
+extern "C" int nerf_hashgrid_scatter_levels(const NerfGridCfg* grid, const NerfPointSrc* src, const NerfLevelSet* levels,
+                                            const float* dfeat, int64_t dfeat_stride, float* dtable, void* stream) {
+    NERF_REQUIRE(grid && dfeat && dtable, "null pointer");
+    NERF_REQUIRE(grid->total_entries < (1ull << 32), "bad grid");
+    int rc = nerf_check_src("nerf_hashgrid_scatter_levels", src, false);
+    if (rc) return rc;
+    rc = check_level_set("nerf_hashgrid_scatter_levels", grid, levels);
+    if (rc) return rc;
+    NERF_REQUIRE(dfeat_stride >= (int64_t)levels->count * grid->n_features, "dfeat_stride smaller than count*F");
+    if (src->n_points == 0 || levels->count == 0) return 0;
+    return launch_scatter(grid, src, nullptr, dfeat, src->n_points, dtable, *levels, dfeat_stride, 0, stream);
+}
+
+extern "C" int nerf_density_from_features(const NerfGridCfg* grid, const NerfNetCfg* net, const float* sigma_params,
+                                          const float* x_hashtable, int64_t n_points, float* sigma, void* stream) {
+    int rc = nerf_check_cfg("nerf_density_from_features", grid, net, false);
+    if (rc) return rc;
+    NERF_REQUIRE(sigma_params && x_hashtable && sigma && n_points >= 0, "null pointer / negative count");
+    if (n_points == 0) return 0;
+    NerfPointSrc src = {};
+    src.n_points = n_points;
+    src.outer_bound = 1.f;
+    return launch_fwd<false, true>(grid, net, nullptr, sigma_params, nullptr, nullptr, &src, sigma, nullptr, nullptr, nullptr,
+                                   x_hashtable, stream);
+}
+
+extern "C" int nerf_field_from_features(const NerfGridCfg* grid, const NerfNetCfg* net, const float* sigma_params,
+                                        const float* color_params, const float* latent_emb, int64_t n_images,
+                                        const NerfPointSrc* src, const float* x_hashtable, float* sigma, float* rgb,
+                                        float* xyz, void* stream) {
+    int rc = nerf_check_cfg("nerf_field_from_features", grid, net, true);
+    if (rc) return rc;
+    rc = nerf_check_src("nerf_field_from_features", src, true);
+    if (rc) return rc;
+    NERF_REQUIRE(sigma_params && color_params && x_hashtable && sigma && rgb, "null pointer");
+    NERF_REQUIRE(net->latent_dim == 0 || (latent_emb && n_images > 0), "latent embedding missing");
+    if (src->n_points == 0) return 0;
+    return launch_fwd<true, true>(grid, net, nullptr, sigma_params, color_params, latent_emb, src, sigma, rgb, nullptr, xyz,
+                                  x_hashtable, stream);
 }

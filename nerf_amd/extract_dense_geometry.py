@@ -45,6 +45,13 @@ class ExtractDenseGeometry():
     @torch.no_grad()
     def extract_dense_geometry(self, N, H, W, K, E, mask=None):
         """allign/extract_dense_geometry.py:58-101.  Returns (points [P,3], colors [P,3]) on the CPU."""
+        if hasattr(self.model, 'local_table') and not getattr(self, '_in_local', False):
+            self._in_local = True       # voxels are sharded by slab: run on the whole local table
+            try:
+                with self.model.local_table():
+                    return self.extract_dense_geometry(N, H, W, K, E, mask)
+            finally:
+                self._in_local = False
         if mask is None:
             mask = self.get_valid_positions(N, H, W, K, E, res=self.mask_res)
         dev = mask.device

@@ -10,6 +10,21 @@ from . import parallel
 from ._lib import check, f32, lib, ptr, stream
 
 
+def _whole_table(fn):
+    """Run a pixel-sharded inference method on the whole local table (a level-sharded model first
+    broadcasts the levels other ranks own; see NeRFNetwork.local_table)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *args, **kwargs):
+        model = getattr(self.renderer, 'model', None)
+        if hasattr(model, 'local_table'):
+            with model.local_table():
+                return fn(self, *args, **kwargs)
+        return fn(self, *args, **kwargs)
+    return wrapped
+
+
 class Inferencer(object):
     def __init__(self, renderer, n_rays, image_num, rotate, max_variance_npy, max_variance_pcd, distribution_area, cams,
                  freq):
@@ -35,6 +50,7 @@ class Inferencer(object):
     def _white(self, device):
         return torch.ones(3, device=device)   # fixed white background (inference.py:80)
 
+    @_whole_table
     @torch.no_grad()
     def render_image(self, n, h, w, K, E, noise=None):
         """inference.py:54-94."""
@@ -72,6 +88,7 @@ class Inferencer(object):
         we = self.calculate_cumlative_weights_thresh(weights, 0.5 + self.distribution_area / 2)
         return (torch.sum(ws * z_vals, dim=-1), torch.sum(wm * z_vals, dim=-1), torch.sum(we * z_vals, dim=-1)), wm
 
+    @_whole_table
     @torch.no_grad()
     def render_invdepth_thresh(self, n, h, w, K, E):
         """inference.py:108-157."""
@@ -91,6 +108,7 @@ class Inferencer(object):
         out_f = parallel.gather_slices(out_l, total)
         return torch.reshape(out_f, h.shape).cpu().numpy()
 
+    @_whole_table
     @torch.no_grad()
     def extract_surface_geometry(self, n, h, w, K, E):
         """inference.py:160-223."""

@@ -174,6 +174,59 @@ class _FieldFn(torch.autograd.Function):
         return dtable, dsw, dcw, dlat, None, None, None
 
 
+class _ShardedFieldFn(torch.autograd.Function):
+    """_FieldFn under a level-sharded table (level_parallel.py): features arrive by all-to-all from the level
+    owners, d(features) returns the same way; only this rank's levels receive table gradient."""
+
+    @staticmethod
+    def forward(ctx, table, sigma_w, color_w, latent, net, src_kwargs, want_xyz):
+        sh = net.level_sharding
+        src = make_point_src(**src_kwargs)
+        M = src.n_points
+        dev = table.device
+        src_all = sh.gather_src(src_kwargs)
+        xh = sh.encode_exchange(table, src_all, M)
+        sigma = torch.empty(M, device=dev, dtype=torch.float32)
+        rgb = torch.empty(M, 3, device=dev, dtype=torch.float32)
+        xyz = torch.empty(M, 3, device=dev, dtype=torch.float32) if want_xyz else None
+        check(lib().nerf_field_from_features(C.byref(net.encoder.cfg), C.byref(net.net_cfg), ptr(sigma_w), ptr(color_w),
+                                             ptr(latent), net.N, C.byref(src), ptr(xh), ptr(sigma), ptr(rgb), ptr(xyz),
+                                             stream()), 'nerf_field_from_features')
+        ctx.net, ctx.src_kwargs, ctx.src_all = net, src_kwargs, src_all
+        ctx.save_for_backward(table, sigma_w, color_w, latent, xh)
+        ctx.mark_non_differentiable(xh)
+        if xyz is not None:
+            ctx.mark_non_differentiable(xyz)
+        return sigma, rgb, xh, xyz
+
+    @staticmethod
+    def backward(ctx, dsigma, drgb, _dxh, _dxyz):
+        table, sigma_w, color_w, latent, xh = ctx.saved_tensors
+        net, sh = ctx.net, ctx.net.level_sharding
+        src = make_point_src(**ctx.src_kwargs)
+        dev = table.device
+        if dsigma is None:
+            dsigma = torch.zeros(src.n_points, device=dev)
+        if drgb is None:
+            drgb = torch.zeros(src.n_points, 3, device=dev)
+        direct = net.direct_grads
+        if direct:
+            dtable, dsw, dcw = table.grad, sigma_w.grad, color_w.grad
+            dlat = latent.grad if latent is not None else None
+        else:
+            dtable, dsw, dcw = torch.zeros_like(table), torch.zeros_like(sigma_w), torch.zeros_like(color_w)
+            dlat = torch.zeros_like(latent) if latent is not None else None
+        dfeat = torch.empty_like(xh)
+        check(lib().nerf_field_bwd(C.byref(net.encoder.cfg), C.byref(net.net_cfg), None, ptr(sigma_w), ptr(color_w),
+                                   ptr(latent), net.N, C.byref(src), ptr(xh), ptr(f32(dsigma)), ptr(f32(drgb)),
+                                   ptr(dfeat), None, ptr(dsw), ptr(dcw), ptr(dlat), stream()), 'nerf_field_bwd')
+        dmine = sh.exchange_dfeat(dfeat)
+        sh.scatter(ctx.src_all, dmine, dtable, net.table_pipeline)
+        if direct:
+            return None, None, None, None, None, None, None
+        return dtable, dsw, dcw, dlat, None, None, None
+
+
 class NeRFNetwork(nn.Module):
     """Same constructor and call surface as the reference NeRFNetwork (nets.py:12-164)."""
 
@@ -217,6 +270,8 @@ class NeRFNetwork(nn.Module):
                                   latent_embedding_dim)
         self.direct_grads = False
         self.table_pipeline = None
+        self.level_sharding = None      # level_parallel.LevelSharding under multi-GPU training
+        self._local_table = 0           # >0: inside `with model.local_table()` (replicated-table kernels)
 
     # ---- gradient plumbing --------------------------------------------------------------
     def enable_direct_grads(self, on=True):
@@ -244,8 +299,39 @@ class NeRFNetwork(nn.Module):
                   'nerf_hashgrid_scatter')
             pipe.level_done(l0, cnt)
 
+    # ---- level-sharded table ----------------------------------------------------------------
+    def shard_levels(self, owner=None):
+        """Shard the hash table by level over the process group (level_parallel.py)."""
+        from .level_parallel import LevelSharding
+        self.level_sharding = LevelSharding(self.encoder.cfg, self.encoder.params.device, owner=owner)
+        return self.level_sharding
+
+    def _sharded(self):
+        return self.level_sharding is not None and self.level_sharding.world > 1 and self._local_table == 0
+
+    def sync_table(self):
+        if self.level_sharding is not None:
+            self.level_sharding.sync_table(self.encoder.params.data)
+
+    def local_table(self):
+        """Context: make the local table whole (broadcast of the levels other ranks own, if stale) and run the
+        single-GPU kernels on it -- for inference, extraction and checkpoints, whose work is sharded by pixel."""
+        net = self
+
+        class _Ctx(object):
+            def __enter__(self_):
+                net.sync_table()
+                net._local_table += 1
+
+            def __exit__(self_, *a):
+                net._local_table -= 1
+        return _Ctx()
+
     # ---- reference surface ----------------------------------------------------------------
     def _field(self, src_kwargs, want_xyz=False):
+        if self._sharded():
+            return _ShardedFieldFn.apply(self.encoder.params, self.sigma_net.params, self.color_net.params,
+                                         self.latent_emb, self, src_kwargs, want_xyz)
         return _FieldFn.apply(self.encoder.params, self.sigma_net.params, self.color_net.params, self.latent_emb, self,
                               src_kwargs, want_xyz)
 
@@ -261,8 +347,21 @@ class NeRFNetwork(nn.Module):
         """nets.py:148-164 (only ever called without grad: renderer.py:145,152)."""
         prefix = x.shape[:-1]
         xx = f32(x).reshape(-1, 3)
-        sigma, xh = self.density_src(make_point_src(outer_bound, x=xx, n_points=xx.shape[0]), want_features=True)
+        sigma, xh = self.density_kw(dict(outer_bound=outer_bound, x=xx, n_points=xx.shape[0]), want_features=True)
         return sigma.reshape(*prefix), {'x_hashtable': xh.reshape(*prefix, -1)}
+
+    @torch.no_grad()
+    def density_kw(self, src_kwargs, want_features=False):
+        """density() on a point source given as make_point_src keyword arguments."""
+        if not self._sharded():
+            return self.density_src(make_point_src(**src_kwargs), want_features)
+        sh = self.level_sharding
+        M = int(src_kwargs['n_points'])
+        xh = sh.encode_exchange(self.encoder.params, sh.gather_src(src_kwargs), M)
+        sigma = torch.empty(M, device=xh.device, dtype=torch.float32)
+        check(lib().nerf_density_from_features(C.byref(self.encoder.cfg), C.byref(self.net_cfg), ptr(self.sigma_net.params),
+                                               ptr(xh), M, ptr(sigma), stream()), 'nerf_density_from_features')
+        return sigma, (xh if want_features else None)
 
     @torch.no_grad()
     def density_src(self, src, want_features=False):

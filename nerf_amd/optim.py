@@ -1,6 +1,8 @@
 """Fused dense Adam (nerf_adam_step) behind torch.optim's param_groups interface, so the
 reference's optimizer wiring (train.py:84-96: three groups, per-group lr / weight_decay,
 LambdaLR on top) works unchanged.  Update rule = torch.optim.Adam's single-tensor path."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -15,13 +17,19 @@ class TablePipeline(object):
     overlap almost perfectly; without the pipeline they run back to back.  Level groups are ordered with the
     large hashed levels first so that the tail left after the last scatter is a small dense level."""
 
-    def __init__(self, grid_cfg, n_features):
+    def __init__(self, grid_cfg, n_features, levels=None, reduce=True):
+        """`levels`: restrict to these levels (the ones this rank owns under a level-sharded table, whose
+        gradient is complete without any all-reduce: pass reduce=False)."""
         L = grid_cfg.n_levels
-        groups = [(l, 1) for l in range(L) if grid_cfg.hashed[l]]
-        dense = [l for l in range(L) if not grid_cfg.hashed[l]]
-        if dense:   # the dense pyramid is small: one group, last
-            groups.append((dense[0], len(dense)))
+        if levels is None:
+            groups = [(l, 1) for l in range(L) if grid_cfg.hashed[l]]
+            dense = [l for l in range(L) if not grid_cfg.hashed[l]]
+            if dense:   # the dense pyramid is small: one group, last
+                groups.append((dense[0], len(dense)))
+        else:       # owned levels are not contiguous: one group each, big hashed levels first
+            groups = [(l, 1) for l in sorted(levels, key=lambda l: (-int(grid_cfg.entries[l]), l))]
         self.groups = groups
+        self.reduce = reduce
         self.slices = {}
         for (l0, cnt) in groups:
             a = int(grid_cfg.offset[l0]) * n_features
@@ -39,7 +47,7 @@ class TablePipeline(object):
         self.works = {}
 
     def level_done(self, l0, cnt):
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if self.reduce and dist.is_initialized() and dist.get_world_size() > 1:
             a, b = self.slices[l0]
             self.works[l0] = dist.all_reduce(self.dtable[a:b], op=dist.ReduceOp.SUM, async_op=True)
         ev = self.events.get(l0)
@@ -55,14 +63,28 @@ class FusedAdam(torch.optim.Optimizer):
         self._grads_cleared = False
         self._table_param = None
         self._pipeline = None
+        self._sharding = None
 
-    def attach(self, model, pipeline=True):
+    def attach(self, model, pipeline=True, shard_levels=None):
         """Give every parameter a persistent .grad and let the model's backward kernel accumulate into
         it directly; the step kernel then clears the gradient in the same pass (zero_grad is free).
-        With `pipeline`, the hash-table update runs as a per-level scatter -> (all-reduce) -> Adam pipeline."""
+        With `pipeline`, the hash-table update runs as a per-level scatter -> (all-reduce) -> Adam pipeline.
+        `shard_levels` (default: on when a process group with more than one rank exists, NERF_TABLE_PARALLEL=0
+        turns it off) shards the hash table by level over the ranks (level_parallel.py): the table then needs
+        no gradient all-reduce and this rank's Adam pass covers only the levels it owns."""
         model.enable_direct_grads(True)
         self._table_param = model.encoder.params
-        if pipeline:
+        self._model = model
+        if shard_levels is None:
+            shard_levels = (dist.is_initialized() and dist.get_world_size() > 1
+                            and os.environ.get('NERF_TABLE_PARALLEL', '1') != '0')
+        if shard_levels:
+            sh = model.shard_levels(None if shard_levels is True else shard_levels)
+            self._sharding = sh
+            model.table_pipeline = TablePipeline(model.encoder.cfg, model.encoder.cfg.n_features, levels=sh.mine,
+                                                 reduce=False)
+            self._pipeline = model.table_pipeline
+        elif pipeline:
             model.table_pipeline = TablePipeline(model.encoder.cfg, model.encoder.cfg.n_features)
             self._pipeline = model.table_pipeline
         return self
@@ -90,6 +112,12 @@ class FusedAdam(torch.optim.Optimizer):
                     st['exp_avg_sq'] = torch.zeros_like(p)
                 st['step'] += 1
                 pipe = self._pipeline
+                if p is self._table_param and self._sharding is not None:
+                    # level-sharded table: only the owned levels have (complete) gradients and moments here
+                    self._sharding.dirty = True
+                    if pipe.pending:
+                        self._pipelined_table_step(p, st, group, b1, b2, pipe)
+                    continue
                 if pipe is not None and p is self._table_param and pipe.pending:
                     self._pipelined_table_step(p, st, group, b1, b2, pipe)
                     continue
@@ -103,6 +131,8 @@ class FusedAdam(torch.optim.Optimizer):
     def table_reduced_by_pipeline(self):
         """True when the pending table gradient is being all-reduced level by level by the pipeline
         (the trainer must then leave the table out of its own gradient all-reduce)."""
+        if self._sharding is not None:
+            return True     # level-sharded: every owner already holds the complete gradient of its levels
         return self._pipeline is not None and self._pipeline.pending and bool(self._pipeline.works)
 
     def _pipelined_table_step(self, p, st, group, b1, b2, pipe):

@@ -31,6 +31,11 @@ def init_from_env(backend=None):
             local = local % torch.cuda.device_count()
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if backend == 'nccl':
+            # create the RCCL communicator now, on the main thread, instead of lazily inside the first
+            # collective (which the training loop issues from autograd's backward thread)
+            dist.all_reduce(torch.zeros(1, device='cuda'))
+            torch.cuda.synchronize()
     if torch.cuda.is_available():
         local = local % torch.cuda.device_count()
     return rank, world, local
@@ -98,3 +103,51 @@ def gather_varlen(local):
     bufs = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(bufs, padded)
     return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+
+
+def _stage_cpu(t):
+    """gloo cannot move device tensors reliably (see tools/gloo_gpu_probe.py): stage through the host."""
+    return dist.get_backend() == 'gloo' and t.is_cuda
+
+
+def all_gather_rows(local):
+    """[R, ...] on every rank -> [world*R, ...], rank-major (equal R on all ranks)."""
+    world = world_size()
+    if world == 1:
+        return local
+    local = local.contiguous()
+    if _stage_cpu(local):
+        src = local.cpu()
+        out = torch.empty((world * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype)
+        dist.all_gather_into_tensor(out, src)
+        return out.to(local.device)
+    out = local.new_empty((world * local.shape[0],) + tuple(local.shape[1:]))
+    dist.all_gather_into_tensor(out, local)
+    return out
+
+
+def all_to_all_flat(send, send_splits, recv_splits):
+    """Flat all-to-all: chunk r of `send` (send_splits[r] elements) goes to rank r; returns the concatenation
+    of the chunks received (recv_splits[r] elements from rank r)."""
+    send = send.contiguous().view(-1)
+    if _stage_cpu(send):
+        s = send.cpu()
+        out = torch.empty(sum(recv_splits), dtype=s.dtype)
+        dist.all_to_all_single(out, s, list(recv_splits), list(send_splits))
+        return out.to(send.device)
+    out = send.new_empty(sum(recv_splits))
+    dist.all_to_all_single(out, send, list(recv_splits), list(send_splits))
+    return out
+
+
+def broadcast_(t, src):
+    """In-place broadcast of a (contiguous view of a) tensor from rank `src`."""
+    if world_size() == 1:
+        return t
+    if _stage_cpu(t):
+        c = t.cpu()
+        dist.broadcast(c, src)
+        t.copy_(c)
+        return t
+    dist.broadcast(t, src)
+    return t

@@ -185,9 +185,8 @@ class NerfRenderer(nn.Module):
         zlog_c, z_c = self._coarse_table(ro.device)
         Sc = zlog_c.shape[0]
         if isinstance(self.model, NeRFNetwork):
-            src = make_point_src(self.outer_bound, rays_o=ro, rays_d=rd, z=z_c, z_stride=0, n_samples=Sc, n_points=N * Sc,
-                                 inner_bound=self.inner_bound)
-            sigmas, _ = self.model.density_src(src)
+            sigmas, _ = self.model.density_kw(dict(outer_bound=self.outer_bound, rays_o=ro, rays_d=rd, z=z_c, z_stride=0,
+                                                   n_samples=Sc, n_points=N * Sc, inner_bound=self.inner_bound))
             sigmas = sigmas.view(N, Sc)
         else:
             z_vals_log, z_vals = self.get_uniform_z_vals(ro, rd, self.steps_firstpass)

@@ -78,9 +78,12 @@ class Trainer(object):
                     self.logger.pointcloud(pointcloud, self.iter, self.inferencer.max_variance_pcd)
 
             if self.save_weights_freq is not None:
-                if (epoch + 1) % self.save_weights_freq == 0 and parallel.rank() == 0:
-                    self.logger.log('Saving Model...')
-                    self.logger.model(self.model, self.iter)
+                if (epoch + 1) % self.save_weights_freq == 0:
+                    if hasattr(self.model, 'sync_table'):
+                        self.model.sync_table()      # level-sharded table: collect every level from its owner (all ranks)
+                    if parallel.rank() == 0:
+                        self.logger.log('Saving Model...')
+                        self.logger.model(self.model, self.iter)
 
     def train_epoch(self, iters_per_epoch):
         for i in range(iters_per_epoch):

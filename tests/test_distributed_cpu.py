@@ -129,3 +129,77 @@ def test_shard_range_covers_everything():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---- level-sharded table: ownership and the two feature exchanges (torch-only part, gloo) ----
+def _fake_cfg(L=7, F=2, log2T=10):
+    from nerf_amd._lib import NerfGridCfg
+    cfg = NerfGridCfg()
+    cfg.n_levels, cfg.n_features, cfg.log2_hashmap_size = L, F, log2T
+    off = 0
+    for l in range(L):
+        cfg.entries[l] = min(1 << log2T, (4 + 3 * l) ** 3)
+        cfg.hashed[l] = 1 if (4 + 3 * l) ** 3 > (1 << log2T) else 0
+        cfg.offset[l] = off
+        off += cfg.entries[l]
+    cfg.total_entries = off
+    return cfg
+
+
+def test_assign_levels_covers_and_balances():
+    from nerf_amd.level_parallel import assign_levels, level_costs
+    cfg = _fake_cfg(L=20, log2T=12)
+    for world in (1, 2, 3, 4, 8):
+        owner = assign_levels(cfg, world)
+        assert len(owner) == 20 and set(owner) <= set(range(world))
+        cost = level_costs(cfg)
+        load = [sum(c for c, o in zip(cost, owner) if o == r) for r in range(world)]
+        assert max(load) - min(load) <= max(cost) + 1e-9       # LPT bound
+
+
+def _exchange_worker(rank, world, port, q):
+    import os
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from nerf_amd.level_parallel import LevelSharding
+    cfg = _fake_cfg()
+    L, F, M = cfg.n_levels, cfg.n_features, 5
+    sh = LevelSharding(cfg, 'cpu')
+    # feature of (owner-of-points r, point p, level l, f) = 1000 r + 100 p + 10 l + f
+    val = lambda r, p, l, f: 1000.0 * r + 100.0 * p + 10.0 * l + f
+    send = torch.tensor([[[val(r, p, l, f) for l in sh.mine for f in range(F)] for p in range(M)] for r in range(world)])
+    xh = sh.exchange_features(send.reshape(-1), M)
+    want = torch.tensor([[val(rank, p, l, f) for l in range(L) for f in range(F)] for p in range(M)])
+    ok_fwd = torch.equal(xh, want)
+    back = sh.exchange_dfeat(want)           # every rank returns its own rows; owners get [world*M, width_mine]
+    want_back = torch.tensor([[val(r, p, l, f) for l in sh.mine for f in range(F)] for r in range(world) for p in range(M)])
+    ok_bwd = torch.equal(back, want_back.reshape(world * M, -1))
+    # table sync: every level comes from its owner
+    table = torch.full((int(cfg.total_entries) * F,), float(rank))
+    sh.dirty = True
+    sh.sync_table(table)
+    ok_sync = all(bool((table[sh.level_slice(l)[0]:sh.level_slice(l)[1]] == sh.owner[l]).all()) for l in range(L))
+    q.put((rank, ok_fwd, ok_bwd, ok_sync, sorted(sh.mine)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_level_sharding_exchanges_gloo():
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    got = [q.get(timeout=120) for _ in range(2)]
+    [p.join(60) for p in procs]
+    owned = []
+    for rank, ok_fwd, ok_bwd, ok_sync, mine in got:
+        assert ok_fwd and ok_bwd and ok_sync, (rank, ok_fwd, ok_bwd, ok_sync)
+        owned += mine
+    assert sorted(owned) == list(range(7))

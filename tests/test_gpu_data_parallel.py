@@ -1,6 +1,8 @@
-"""Data-parallel training on the GPU path: two ranks (gloo, both on cuda:0 -- the test box has one GPU) each
-train on their half of every batch through the per-level scatter -> all-reduce -> Adam pipeline; the result must
-equal one process training on the whole batch (mean-over-rays loss => SUM of shard grads / world)."""
+"""Multi-rank training on the GPU path: two ranks (gloo, both on cuda:0 -- the test box has one GPU) each train on
+their half of every batch; the result must equal one process training on the whole batch (mean-over-rays loss =>
+SUM of shard grads / world).  Two table strategies:
+  'dp'       replicated table, per-level scatter -> all-reduce -> Adam pipeline;
+  'sharded'  level-sharded table (level_parallel.py): feature all-to-all, no table all-reduce, owner-only Adam."""
 import os
 import socket
 
@@ -53,15 +55,19 @@ def _train(rank, world):
         loss.backward()
         if world > 1:
             skip = [opt._table_param] if opt.table_reduced_by_pipeline() else []
-            assert skip, 'the table gradient must be reduced by the pipeline'
+            assert skip, 'the table gradient must not need an all-reduce of its own'
             parallel.all_reduce_grads([p for g in opt.param_groups for p in g['params']], skip=skip)
             opt.grad_scale = 1.0 / world
         opt.step()
+    if world > 1:
+        assert (net.level_sharding is not None) == (os.environ.get('NERF_TABLE_PARALLEL') != '0')
+    net.sync_table()
     torch.cuda.synchronize()
     return [p.detach().cpu() for p in (net.encoder.params, net.sigma_net.params, net.color_net.params, net.latent_emb)]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, mode):
+    os.environ['NERF_TABLE_PARALLEL'] = '1' if mode == 'sharded' else '0'
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -72,14 +78,15 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_training_matches_single_process():
+@pytest.mark.parametrize('mode', ['dp', 'sharded'])
+def test_two_rank_training_matches_single_process(mode):
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, mode)) for r in range(2)]
     [p.start() for p in procs]
     got = q.get(timeout=150)
     [p.join(60) for p in procs]

@@ -1,0 +1,97 @@
+"""Level-sharded table, single process: the cut entry points (encode a level subset / MLPs from ready features /
+scatter a level subset) must reproduce the fused kernels they were cut from -- bit-exactly in the forward
+direction (same arithmetic in the same order), to atomic-ordering noise in the scatter."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from test_gpu_parity import NET_CFGS, _make_pair  # noqa: E402
+
+
+def _rays(M_rays, S, seed):
+    g = torch.Generator().manual_seed(seed)
+    ro = (torch.rand(M_rays, 3, generator=g) * 2 - 1) * 1.5
+    rd = torch.randn(M_rays, 3, generator=g)
+    z = torch.sort(torch.rand(M_rays, S, generator=g) * 3 + 0.3, dim=-1).values
+    n = torch.randint(0, 7, (M_rays,), generator=g)
+    return ro.cuda(), rd.cuda(), z.cuda().contiguous(), n.cuda()
+
+
+@pytest.mark.parametrize('name', list(NET_CFGS))
+@pytest.mark.parametrize('world', [2, 3])
+def test_cut_entry_points_match_fused(name, world):
+    from nerf_amd._lib import check, lib, ptr, stream
+    from nerf_amd.level_parallel import LevelSharding
+    from nerf_amd.nets import make_point_src
+    net, _ = _make_pair(NET_CFGS[name])
+    cfg, ncfg = net.encoder.cfg, net.net_cfg
+    L, F = cfg.n_levels, cfg.n_features
+    R, S = 37, 13                                    # ragged: 481 points
+    ro, rd, z, n = _rays(R, S, 5)
+    M = R * S
+    kw = dict(outer_bound=2.5, inner_bound=2.0, rays_o=ro, rays_d=rd, z=z, z_stride=S, n_samples=S, n_points=M, n=n)
+    # fused reference
+    sig_f, rgb_f, xh_f, xyz_f = net._field(kw, want_xyz=True)
+    sig_d, xh_d = net.density_src(make_point_src(**kw), want_features=True)
+    assert torch.equal(xh_f, xh_d)
+    # every "rank" encodes its levels; assemble like exchange_features does
+    shards = [LevelSharding(cfg, 'cuda', rank=r, world=world) for r in range(world)]
+    assert sorted(l for s in shards for l in s.mine) == list(range(L))
+    src = make_point_src(**kw)
+    chunks = []
+    for s in shards:
+        w = s.width[s.rank]
+        out = torch.full((M, max(w, 1)), float('nan'), device='cuda')
+        if w:
+            check(lib().nerf_hashgrid_encode_levels(C.byref(cfg), ptr(net.encoder.params), C.byref(src), C.byref(s.my_set),
+                                                    ptr(out), w, stream()), 'encode_levels')
+        chunks.append(out[:, :w])
+    xh = torch.cat(chunks, 1).index_select(1, shards[0].inv).contiguous()
+    assert torch.equal(xh, xh_f.detach())
+    # MLP halves from ready features
+    sig2 = torch.empty(M, device='cuda')
+    check(lib().nerf_density_from_features(C.byref(cfg), C.byref(ncfg), ptr(net.sigma_net.params), ptr(xh), M, ptr(sig2),
+                                           stream()), 'density_from_features')
+    assert torch.equal(sig2, sig_d)
+    sig3, rgb3, xyz3 = torch.empty(M, device='cuda'), torch.empty(M, 3, device='cuda'), torch.empty(M, 3, device='cuda')
+    check(lib().nerf_field_from_features(C.byref(cfg), C.byref(ncfg), ptr(net.sigma_net.params), ptr(net.color_net.params),
+                                         ptr(net.latent_emb), net.N, C.byref(src), ptr(xh), ptr(sig3), ptr(rgb3), ptr(xyz3),
+                                         stream()), 'field_from_features')
+    assert torch.equal(sig3, sig_f.detach()) and torch.equal(rgb3, rgb_f.detach()) and torch.equal(xyz3, xyz_f)
+    # scatter of level subsets == the per-level slices of the whole scatter
+    dfeat = torch.randn(M, L * F, device='cuda')
+    whole = torch.zeros_like(net.encoder.params)
+    check(lib().nerf_hashgrid_scatter(C.byref(cfg), C.byref(src), ptr(dfeat), ptr(whole), 0, L, stream()), 'scatter')
+    parts = torch.zeros_like(net.encoder.params)
+    for s in shards:
+        w = s.width[s.rank]
+        if not w:
+            continue
+        mine = dfeat.index_select(1, s.perm).split(s.width, 1)[s.rank].contiguous()
+        check(lib().nerf_hashgrid_scatter_levels(C.byref(cfg), C.byref(src), C.byref(s.my_set), ptr(mine), w, ptr(parts),
+                                                 stream()), 'scatter_levels')
+    torch.testing.assert_close(parts, whole, rtol=1e-5, atol=1e-5 * float(whole.abs().max()))
+
+
+def test_level_entry_points_reject_bad_arguments():
+    from nerf_amd._lib import NerfLevelSet, lib, ptr, stream
+    from nerf_amd.nets import make_point_src
+    net, _ = _make_pair(NET_CFGS['odd'])
+    cfg = net.encoder.cfg
+    x = torch.rand(8, 3, device='cuda')
+    src = make_point_src(2.5, x=x, n_points=8)
+    out = torch.empty(8, 4, device='cuda')
+    bad = NerfLevelSet()
+    bad.count, bad.level[0] = 1, cfg.n_levels          # level out of range
+    assert lib().nerf_hashgrid_encode_levels(C.byref(cfg), ptr(net.encoder.params), C.byref(src), C.byref(bad), ptr(out), 4,
+                                             stream()) == -1
+    ok = NerfLevelSet()
+    ok.count, ok.level[0], ok.level[1] = 2, 0, 3
+    assert lib().nerf_hashgrid_encode_levels(C.byref(cfg), ptr(net.encoder.params), C.byref(src), C.byref(ok), ptr(out), 3,
+                                             stream()) == -1      # stride < count*F
+    assert lib().nerf_hashgrid_encode_levels(C.byref(cfg), ptr(net.encoder.params), C.byref(src), C.byref(ok), ptr(out), 4,
+                                             stream()) == 0
+    torch.cuda.synchronize()
