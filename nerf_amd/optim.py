@@ -6,6 +6,7 @@ import os
 import torch
 import torch.distributed as dist
 
+from . import parallel
 from ._lib import check, lib, ptr, stream
 
 
@@ -49,7 +50,7 @@ class TablePipeline(object):
     def level_done(self, l0, cnt):
         if self.reduce and dist.is_initialized() and dist.get_world_size() > 1:
             a, b = self.slices[l0]
-            self.works[l0] = dist.all_reduce(self.dtable[a:b], op=dist.ReduceOp.SUM, async_op=True)
+            self.works[l0] = parallel.all_reduce_sum_(self.dtable[a:b], async_op=True)
         ev = self.events.get(l0)
         if ev is None:
             ev = self.events[l0] = torch.cuda.Event()

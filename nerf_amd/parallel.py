@@ -56,6 +56,17 @@ def shard_range(total, rank_, world):
     return start, start + base + (1 if rank_ < rem else 0)
 
 
+def all_reduce_sum_(t, async_op=False):
+    """In-place SUM all-reduce.  Returns a work handle when async_op and the backend runs it asynchronously
+    (None otherwise: gloo moves device tensors through the host, synchronously -- see _stage_cpu)."""
+    if _stage_cpu(t):
+        c = t.cpu()
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        t.copy_(c)
+        return None
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op)
+
+
 def all_reduce_grads(params, async_op=False, skip=()):
     """SUM-all-reduce the .grad of every parameter (largest first so the big transfer starts early).
     `skip`: parameters whose gradient is reduced elsewhere (the pipelined hash table).
@@ -66,8 +77,8 @@ def all_reduce_grads(params, async_op=False, skip=()):
     skip_ids = {id(p) for p in skip}
     for p in sorted((p for p in params if p is not None and p.grad is not None and id(p) not in skip_ids),
                     key=lambda t: -t.numel()):
-        h = dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=async_op)
-        if async_op:
+        h = all_reduce_sum_(p.grad, async_op=async_op)
+        if async_op and h is not None:
             handles.append(h)
     return handles
 
@@ -83,9 +94,20 @@ def gather_slices(local, total, dim=0):
     pad_shape[dim] = maxlen
     padded = local.new_zeros(pad_shape)
     padded.narrow(dim, 0, local.shape[dim]).copy_(local)
-    bufs = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(bufs, padded)
+    bufs = _all_gather_list(padded)
     return torch.cat([b.narrow(dim, 0, e - s) for b, (s, e) in zip(bufs, sizes)], dim=dim)
+
+
+def _all_gather_list(t):
+    world = world_size()
+    if _stage_cpu(t):
+        c = t.cpu()
+        bufs = [torch.empty_like(c) for _ in range(world)]
+        dist.all_gather(bufs, c)
+        return [b.to(t.device) for b in bufs]
+    bufs = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(bufs, t)
+    return bufs
 
 
 def gather_varlen(local):
@@ -94,14 +116,11 @@ def gather_varlen(local):
     if world == 1:
         return local
     count = torch.tensor([local.shape[0]], device=local.device, dtype=torch.int64)
-    counts = [torch.zeros_like(count) for _ in range(world)]
-    dist.all_gather(counts, count)
-    counts = [int(c.item()) for c in counts]
+    counts = [int(c.item()) for c in _all_gather_list(count)]
     maxlen = max(max(counts), 1)
     padded = local.new_zeros((maxlen,) + tuple(local.shape[1:]))
     padded[:local.shape[0]] = local
-    bufs = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(bufs, padded)
+    bufs = _all_gather_list(padded)
     return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
 
 
