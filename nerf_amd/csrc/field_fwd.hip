@@ -143,13 +143,19 @@ __global__ __launch_bounds__(256) void encode_levels_kernel(GridDev g, const flo
 // (point, level) touch ~4-5 lines (corner pairs along x and the F features of an entry share a
 // line) instead of one line per lane -- measured 3.4x faster than one thread per (point, level).
 // grid.y = level, so the level parameters are scalar.
-// Level slot blockIdx.y handles level set.level[y]; its F gradient columns sit at dfeat[p*stride + col0 + y*F].
+// Level slot blockIdx.y handles level plan.level[y]; its F gradient columns sit at dfeat[p*stride + plan.col[y]].
+struct ScatterPlan {
+    int count;
+    int level[NERF_MAX_LEVELS];
+    int col[NERF_MAX_LEVELS];
+};
+
 template <int F>
 __global__ __launch_bounds__(256) void scatter_kernel(GridDev g, NerfPointSrc src, const float* __restrict__ x01,
                                                       const float* __restrict__ dfeat, int64_t M,
-                                                      float* __restrict__ dtable, NerfLevelSet set, int64_t stride,
-                                                      int col0) {
-    const int l = set.level[blockIdx.y];
+                                                      float* __restrict__ dtable, ScatterPlan plan, int64_t stride) {
+    const int l = plan.level[blockIdx.y];
+    const int col0 = plan.col[blockIdx.y];
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t p = t / (8 * F);
     if (p >= M) return;
@@ -167,7 +173,78 @@ __global__ __launch_bounds__(256) void scatter_kernel(GridDev g, NerfPointSrc sr
     uint32_t idx;
     if (g.hashed[l]) idx = (cx ^ (cy * 2654435761u) ^ (cz * 805459861u)) & (entries - 1u);
     else { idx = cx + cy * res + cz * (res * res); if (idx >= entries) idx %= entries; }
-    atomicAdd(dtable + ((size_t)g.offset[l] + idx) * F + f, w * dfeat[p * stride + col0 + (int)blockIdx.y * F + f]);
+    atomicAdd(dtable + ((size_t)g.offset[l] + idx) * F + f, w * dfeat[p * stride + col0 + f]);
+}
+
+// Small dense levels (the coarse end of the pyramid: 4 K .. 64 K entries) receive millions of atomics on a
+// few hundred cache lines; at the memory side those serialise (level 0 alone cost as much as six hashed
+// levels).  Here every workgroup accumulates into a private copy of (a chunk of) the level in LDS with
+// ds_add_f32 and flushes the copy once with global atomics.  grid = (blocks per chunk, chunks);
+// a chunk is `chunk_entries` consecutive entries of the level.
+constexpr int kSmallLdsFloats = 32768;   // 128 KB of the 160 KB LDS
+constexpr int kSmallMaxChunks = 16;
+constexpr int kSmallThreads = 1024;
+
+template <int F>
+__global__ __launch_bounds__(kSmallThreads) void scatter_small_kernel(GridDev g, NerfPointSrc src,
+                                                                      const float* __restrict__ x01,
+                                                                      const float* __restrict__ dfeat, int64_t M,
+                                                                      float* __restrict__ dtable, int l, int col0,
+                                                                      int64_t stride, int chunk_entries, int transpose) {
+    extern __shared__ __attribute__((aligned(16))) float acc[];
+    const uint32_t res = g.res[l], entries = g.entries[l], res2 = res * res;
+    const uint32_t lo = blockIdx.y * (uint32_t)chunk_entries;
+    const uint32_t n_here = min((uint32_t)chunk_entries, entries - lo);
+    for (uint32_t i = threadIdx.x; i < n_here * F; i += blockDim.x) acc[i] = 0.f;
+    __syncthreads();
+    const float sc = g.scale[l];
+    // Neighbouring samples of one ray fall into the same coarse cell, and ds_add_f32 serialises lanes that
+    // hit one address: the coarsest levels walk the points "transposed" (consecutive lanes = the same sample of
+    // consecutive rays).  Levels cut into many chunks keep the natural order: their cells are smaller and most
+    // visits only read a depth and reject, which wants coalesced reads.
+    const int64_t cols = src.mode == 1 ? src.n_samples : 64;
+    const int64_t rows = M / cols, body = transpose ? rows * cols : 0;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < M; v += (int64_t)gridDim.x * blockDim.x) {
+        int64_t p = v;
+        if (v < body) { const int64_t c = (int64_t)((uint64_t)v / (uint64_t)rows); p = (v - c * rows) * cols + c; }
+        float x, y, z;
+        if (x01) { x = x01[p * 3]; y = x01[p * 3 + 1]; z = x01[p * 3 + 2]; }
+        else { const PointIn q = fetch_point(src, p, false); x = q.x; y = q.y; z = q.z; }
+        const float px = fmaf(x, sc, 0.5f), py = fmaf(y, sc, 0.5f), pz = fmaf(z, sc, 0.5f);
+        const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+        const float wx = px - fx, wy = py - fy, wz = pz - fz;
+        const uint32_t ix = (uint32_t)(int)fx, iy = (uint32_t)(int)fy, iz = (uint32_t)(int)fz;
+        // in-range points put their 8 corners in [iz*res2, (iz+3)*res2): skip those whose z slab misses this
+        // chunk (not near the wrap-around of the dense index at the top of the level, nor for stray points)
+        if (ix < res && iy < res && (uint64_t)(iz + 3) * res2 <= entries &&
+            ((iz + 3) * res2 <= lo || iz * res2 >= lo + n_here)) continue;
+        float d[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) d[f] = dfeat[p * stride + col0 + f];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t cx = ix + (k & 1), cy = iy + ((k >> 1) & 1), cz = iz + ((k >> 2) & 1);
+            const float w = __fmul_rn(__fmul_rn((k & 1) ? wx : 1.f - wx, (k & 2) ? wy : 1.f - wy), (k & 4) ? wz : 1.f - wz);
+            uint32_t idx = cx + cy * res + cz * res2;
+            if (idx >= entries) idx %= entries;
+            const uint32_t rel = idx - lo;
+            if (rel < n_here) {
+#pragma unroll
+                for (int f = 0; f < F; ++f) atomicAdd(acc + rel * F + f, w * d[f]);
+            }
+        }
+    }
+    __syncthreads();
+    // flush; every block starts its sweep at a different place so that the blocks do not chase each other
+    const uint32_t n = n_here * F;
+    const uint32_t start = (uint32_t)(((uint64_t)blockIdx.x * n) / gridDim.x);
+    float* dst = dtable + ((size_t)g.offset[l] + lo) * F;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        uint32_t j = i + start;
+        if (j >= n) j -= n;
+        const float v = acc[j];
+        if (v != 0.f) atomicAdd(dst + j, v);
+    }
 }
 
 __global__ void sh_fwd_kernel(const float* __restrict__ d01, int64_t M, int dim, float* __restrict__ out) {
@@ -335,19 +412,55 @@ static int check_level_set(const char* fn, const NerfGridCfg* grid, const NerfLe
 static int launch_scatter(const NerfGridCfg* grid, const NerfPointSrc* src, const float* x01, const float* dfeat,
                           int64_t n_points, float* dtable, const NerfLevelSet& set, int64_t stride, int col0, void* stream) {
     const GridDev g = make_grid_dev(grid);
-    const int n_levels = set.count;
     NerfPointSrc s = {};
     if (src) s = *src;
     hipStream_t st = (hipStream_t)stream;
     const int F = grid->n_features;
-    const dim3 nb((unsigned)ceil_div64(n_points * 8 * F, 256), (unsigned)n_levels);
-    switch (F) {
-        case 1: scatter_kernel<1><<<nb, 256, 0, st>>>(g, s, x01, dfeat, n_points, dtable, set, stride, col0); break;
-        case 2: scatter_kernel<2><<<nb, 256, 0, st>>>(g, s, x01, dfeat, n_points, dtable, set, stride, col0); break;
-        case 4: scatter_kernel<4><<<nb, 256, 0, st>>>(g, s, x01, dfeat, n_points, dtable, set, stride, col0); break;
-        default: nerf_set_error("scatter: unsupported n_features"); return NERF_EUNSUPPORTED;
+    if (F != 1 && F != 2 && F != 4) { nerf_set_error("scatter: unsupported n_features"); return NERF_EUNSUPPORTED; }
+    // small dense levels go through the LDS-privatised kernel (worth it once there are enough points to
+    // amortise the flush), everything else through the lane-grouped global-atomic kernel
+    ScatterPlan plan = {};
+    for (int i = 0; i < set.count; ++i) {
+        const int l = set.level[i], col = col0 + i * F;
+        const int64_t floats = (int64_t)grid->entries[l] * F;
+        const bool small = !grid->hashed[l] && floats <= (int64_t)kSmallLdsFloats * kSmallMaxChunks && n_points >= 65536;
+        if (!small) {
+            plan.level[plan.count] = l;
+            plan.col[plan.count++] = col;
+            continue;
+        }
+        const int chunks = (int)ceil_div64(floats, kSmallLdsFloats);
+        const int chunk_entries = (int)ceil_div64(grid->entries[l], chunks);
+        const int lds_bytes = chunk_entries * F * (int)sizeof(float);
+        int64_t per_chunk = kNumCU / chunks;
+        const int64_t want = ceil_div64(n_points, kSmallThreads);
+        if (per_chunk > want) per_chunk = want;
+        if (per_chunk < 1) per_chunk = 1;
+        const dim3 nb((unsigned)per_chunk, (unsigned)chunks);
+#define LAUNCH_SMALL(FF)                                                                                                  \
+        do {                                                                                                              \
+            auto kern = scatter_small_kernel<FF>;                                                                         \
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
+            if (e != hipSuccess) { nerf_set_error("scatter: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }   \
+            kern<<<nb, kSmallThreads, lds_bytes, st>>>(g, s, x01, dfeat, n_points, dtable, l, col, stride, chunk_entries,  \
+                                                       chunks <= 2);                                                \
+        } while (0)
+        switch (F) {
+            case 1: LAUNCH_SMALL(1); break;
+            case 2: LAUNCH_SMALL(2); break;
+            default: LAUNCH_SMALL(4); break;
+        }
+#undef LAUNCH_SMALL
     }
-    return nerf_launch_status("nerf_hashgrid_bwd");
+    if (plan.count > 0) {
+        const dim3 nb((unsigned)ceil_div64(n_points * 8 * F, 256), (unsigned)plan.count);
+        switch (F) {
+            case 1: scatter_kernel<1><<<nb, 256, 0, st>>>(g, s, x01, dfeat, n_points, dtable, plan, stride); break;
+            case 2: scatter_kernel<2><<<nb, 256, 0, st>>>(g, s, x01, dfeat, n_points, dtable, plan, stride); break;
+            default: scatter_kernel<4><<<nb, 256, 0, st>>>(g, s, x01, dfeat, n_points, dtable, plan, stride); break;
+        }
+    }
+    return nerf_launch_status("nerf_hashgrid_scatter");
 }
 
 int nerf_hashgrid_bwd(const NerfGridCfg* grid, const float* x01, const float* dout, int64_t n_points, float* dtable,

@@ -30,21 +30,56 @@ from ._lib import NerfLevelSet, check, lib, ptr, stream
 
 
 def level_costs(cfg):
-    """Relative per-level cost of owning a level (gathers + atomics on it): hashed levels are HBM-random,
-    small dense levels mostly hit L2."""
-    T = float(1 << cfg.log2_hashmap_size)
-    return [1.0 if cfg.hashed[l] else 0.3 + 0.7 * min(1.0, cfg.entries[l] / T) for l in range(cfg.n_levels)]
+    """Relative per-level cost of owning a level (encode gathers + scatter atomics + Adam on it), from
+    tools/shard_emulate.py --per-level on MI355X (profiles/r01_shard_emulate_w8.log): a level's scatter runs at the
+    memory-side atomic rate whatever its size (~0.9 ms for 4.2 M points), except for the small dense levels that
+    the LDS-privatised kernel handles; the gathers of both passes add 0.05 (dense, L2-resident) to 0.5 (finest
+    hashed level)."""
+    out = []
+    hashed = [l for l in range(cfg.n_levels) if cfg.hashed[l]]
+    for l in range(cfg.n_levels):
+        floats = cfg.entries[l] * cfg.n_features
+        if cfg.hashed[l]:
+            out.append(1.15 + 0.25 * (l - hashed[0]) / max(1, len(hashed) - 1))
+        elif floats <= 2 * 32768:
+            out.append(0.4)
+        elif floats <= 16 * 32768:
+            out.append(0.95)
+        else:
+            out.append(1.1)
+    return out
 
 
 def assign_levels(cfg, world):
-    """owner[l] for every level: longest-processing-time greedy on level_costs (deterministic)."""
+    """owner[l] for every level: longest-processing-time greedy on level_costs, then moves / swaps while they
+    lower the sum of squared loads (deterministic; identical on every rank)."""
     cost = level_costs(cfg)
+    L = cfg.n_levels
     load = [0.0] * world
-    owner = [0] * cfg.n_levels
-    for l in sorted(range(cfg.n_levels), key=lambda l: (-cost[l], l)):
+    owner = [0] * L
+    for l in sorted(range(L), key=lambda l: (-cost[l], l)):
         r = min(range(world), key=lambda r: (load[r], r))
         owner[l] = r
         load[r] += cost[l]
+    improved = True
+    while improved:
+        improved = False
+        for l in range(L):
+            for r in range(world):          # move l to r
+                a = owner[l]
+                if r != a and (load[r] + cost[l]) ** 2 + (load[a] - cost[l]) ** 2 < load[r] ** 2 + load[a] ** 2 - 1e-12:
+                    load[a] -= cost[l]
+                    load[r] += cost[l]
+                    owner[l] = r
+                    improved = True
+            for k in range(l + 1, L):       # swap l and k
+                a, b = owner[l], owner[k]
+                d = cost[l] - cost[k]
+                if a != b and (load[a] - d) ** 2 + (load[b] + d) ** 2 < load[a] ** 2 + load[b] ** 2 - 1e-12:
+                    load[a] -= d
+                    load[b] += d
+                    owner[l], owner[k] = b, a
+                    improved = True
     return owner
 
 

@@ -95,3 +95,41 @@ def test_level_entry_points_reject_bad_arguments():
     assert lib().nerf_hashgrid_encode_levels(C.byref(cfg), ptr(net.encoder.params), C.byref(src), C.byref(ok), ptr(out), 4,
                                              stream()) == 0
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize('name', ['small', 'base19'])
+def test_lds_privatised_scatter_matches_global_atomic_path(name):
+    """Calls with >= 65536 points send the small dense levels through the LDS-privatised kernel (one and several
+    chunks per level); the same points in pieces below that bar take the global-atomic kernel.  Same sums."""
+    from nerf_amd._lib import check, lib, ptr, stream
+    from nerf_amd.nets import make_point_src
+    net, _ = _make_pair(NET_CFGS[name])
+    cfg = net.encoder.cfg
+    L, F = cfg.n_levels, cfg.n_features
+    R, S = 1171, 64                                   # 74944 points, ragged against 1024-thread blocks
+    ro, rd, z, _ = _rays(R, S, 9)
+    M = R * S
+    dfeat = torch.randn(M, L * F, device='cuda')
+    src = make_point_src(2.5, rays_o=ro, rays_d=rd, z=z, z_stride=S, n_samples=S, n_points=M, inner_bound=2.0)
+    got = torch.zeros_like(net.encoder.params)
+    check(lib().nerf_hashgrid_scatter(C.byref(cfg), C.byref(src), ptr(dfeat), ptr(got), 0, L, stream()), 'scatter')
+    want = torch.zeros_like(net.encoder.params)
+    step = 500                                        # rays per piece: 32000 points
+    for a in range(0, R, step):
+        b = min(R, a + step)
+        part = make_point_src(2.5, rays_o=ro[a:b].contiguous(), rays_d=rd[a:b].contiguous(), z=z[a:b].contiguous(),
+                              z_stride=S, n_samples=S, n_points=(b - a) * S, inner_bound=2.0)
+        check(lib().nerf_hashgrid_scatter(C.byref(cfg), C.byref(part), ptr(dfeat[a * S:b * S].contiguous()), ptr(want), 0, L,
+                                          stream()), 'scatter')
+    small = [l for l in range(L) if not cfg.hashed[l] and cfg.entries[l] * F <= 4 * 32768]
+    assert small, 'configuration has no small dense level'
+    torch.testing.assert_close(got, want, rtol=1e-4, atol=2e-5 * float(want.abs().max()))
+    # and in points mode through the stand-alone encoding backward
+    x01 = torch.rand(M, 3, device='cuda')
+    got2, want2 = torch.zeros_like(got), torch.zeros_like(got)
+    check(lib().nerf_hashgrid_bwd(C.byref(cfg), ptr(x01), ptr(dfeat), M, ptr(got2), stream()), 'bwd')
+    for a in range(0, M, 30000):
+        b = min(M, a + 30000)
+        check(lib().nerf_hashgrid_bwd(C.byref(cfg), ptr(x01[a:b].contiguous()), ptr(dfeat[a:b].contiguous()), b - a,
+                                      ptr(want2), stream()), 'bwd')
+    torch.testing.assert_close(got2, want2, rtol=1e-4, atol=2e-5 * float(want2.abs().max()))
