@@ -193,32 +193,53 @@ def main():
         train_step(model, renderer, loader, opt, args.rays, it, world)
     prof = _lib.kernel_timing(False) if args.profile_steps > 0 else {}
     kernels = []
+    n_pts_scatter = args.rays * SF * (world if model_sharded is not None else 1)
     for name, (launches, total_ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
         per_step_ms = total_ms / args.profile_steps
-        if name == 'nerf_adam_step':
-            bytes_step = 32 * n_params                       # all slices / tensors of one step together
-        elif name in ('nerf_hashgrid_scatter', 'nerf_hashgrid_scatter_levels', 'nerf_hashgrid_encode_levels'):
-            bytes_step = algorithmic_bytes(name, args.rays, n_params)   # the per-level launches of one step together
+        base = name.split('[')[0]
+        cls = name[len(base):]
+        # algorithmic bytes of ALL launches of this class in one step
+        if base == 'nerf_adam_step':
+            bytes_step = None
+            if cls.startswith('[table slice'):          # 32 B / parameter: p, g, m, v read; p, m, v written, g cleared
+                bytes_step = 32 * float(cls.split(',')[1].split('M')[0]) * 1e6 * (launches / args.profile_steps)
+        elif base in ('nerf_hashgrid_scatter', 'nerf_hashgrid_scatter_levels'):
+            lv = int(cls[1:].split(' ')[0])             # levels per launch
+            per_level = n_pts_scatter * (2 * 8 * 2 * 4 + 2 * 4)     # RMW of 8 corners x F floats + F floats of dfeat
+            bytes_step = per_level * lv * (launches / args.profile_steps)
+        elif base == 'nerf_hashgrid_encode_levels':
+            bytes_step = algorithmic_bytes(base, args.rays, n_params)   # both launches of one step together
         else:
-            b = algorithmic_bytes(name, args.rays, n_params)
+            b = algorithmic_bytes(base, args.rays, n_params)
             bytes_step = b * (launches / args.profile_steps) if b else None
-        k = {'name': name, 'launches_per_step': launches / args.profile_steps, 'ms_per_step': round(per_step_ms, 4)}
+        k = {'name': name, 'launches_per_step': launches / args.profile_steps, 'ms_per_step': round(per_step_ms, 4),
+             'avg_launch_ms': round(total_ms / launches, 4)}
         if bytes_step:
+            k['algorithmic_bytes_per_launch'] = bytes_step / (launches / args.profile_steps)
             k['algorithmic_GBps'] = round(bytes_step / (per_step_ms * 1e-3) / 1e9, 1)
             k['hbm_frac'] = round(k['algorithmic_GBps'] / HBM_PEAK_GBS, 4)
-        fl = algorithmic_flops(name, args.rays)
+        fl = algorithmic_flops(base, args.rays)
         if fl:
             k['algorithmic_TFLOPs'] = round(fl / (per_step_ms * 1e-3) / 1e12, 2)
             k['mfma_f32_frac'] = round(k['algorithmic_TFLOPs'] / MFMA_F32_PEAK_TFLOPS, 4)
         kernels.append(k)
-    dom = kernels[0] if kernels else {'name': None, 'ms_per_step': 0.0, 'launches_per_step': 1.0}
-    traffic = None
     tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
-    if os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get(dom['name'])
-    roofline = {'kernel': dom['name'], 'bound': 'hbm', 'achieved': dom.get('algorithmic_GBps'), 'peak': HBM_PEAK_GBS,
-                'unit': 'GB/s', 'frac': dom.get('hbm_frac'), 'traffic': traffic,
-                'avg_launch_ms': round(dom['ms_per_step'] / dom['launches_per_step'], 4)}
+    pmc = json.load(open(tpath)) if os.path.exists(tpath) else {}
+
+    def roofline_of(k):
+        # HBM bytes per launch from the committed PMC passes (tools/pmc_summary.py), same launch class
+        rec = pmc.get('per_launch', {}).get(k['name']) or pmc.get('per_launch', {}).get(k['name'].split(',')[0] + ']')
+        return {'kernel': k['name'], 'bound': 'hbm', 'achieved': k.get('algorithmic_GBps'), 'peak': HBM_PEAK_GBS,
+                'unit': 'GB/s', 'frac': k.get('hbm_frac'), 'traffic': rec['hbm_bytes'] if rec else None,
+                'avg_launch_ms': k['avg_launch_ms'], 'launches_per_step': k['launches_per_step'],
+                'algorithmic_bytes_per_launch': k.get('algorithmic_bytes_per_launch')}
+    with_bytes = [k for k in kernels if k.get('algorithmic_GBps')]
+    roofline = roofline_of(with_bytes[0]) if with_bytes else None
+    if roofline and roofline['kernel'].startswith('nerf_hashgrid_scatter'):
+        roofline['note'] = ('random 8-byte atomic adds: bounded by the memory-side atomic rate (one 64-B request per table '
+                            'entry), not by bytes; the launches overlap the Adam pass of the previous level')
+    # the second-largest class, for reference (the Adam pass streams at the HBM roofline)
+    roofline_2 = roofline_of(with_bytes[1]) if len(with_bytes) > 1 else None
 
     # ---- 800x800 inference (BASELINE configs[1]) ----
     render = None
@@ -255,7 +276,7 @@ def main():
                                    'procedural scene 100 poses 800x800' % (args.rays, args.table_log2),
                        'rays_per_gpu': args.rays, 'global_rays': args.rays * world, 'parallelism': ('dp%d over rays' % world) + (', hash table sharded by level (feature all-to-all)'
                                                                     if getattr(model_sharded, 'world', 1) > 1 else '')},
-            'roofline': roofline, 'cpu_baseline': cpu, 'render': render, 'kernels': kernels,
+            'roofline': roofline, 'roofline_second': roofline_2, 'cpu_baseline': cpu, 'render': render, 'kernels': kernels,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

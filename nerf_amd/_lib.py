@@ -90,8 +90,27 @@ class _Timed(object):
         a.record()
         rc = self.fn(*args)
         b.record()
-        _prof.setdefault(self.name, []).append((a, b))
+        _prof.setdefault(self.name + _launch_class(self.name, args), []).append((a, b))
         return rc
+
+
+def _launch_class(name, args):
+    """Entry points whose launches differ a lot in size are timed per size class, so that one class is one
+    kernel at one problem size (what a roofline figure needs)."""
+    if name == 'nerf_hashgrid_scatter':
+        grid, l0, cnt = args[0]._obj, args[4], args[5]
+        if cnt == 1:
+            return '[1 hashed level]' if grid.hashed[l0] else '[1 dense level]'
+        return '[%d dense levels]' % cnt
+    if name == 'nerf_hashgrid_scatter_levels':
+        grid, ls = args[0]._obj, args[2]._obj
+        if ls.count == 1:
+            return '[1 hashed level]' if grid.hashed[ls.level[0]] else '[1 dense level]'
+        return '[%d levels]' % ls.count
+    if name == 'nerf_adam_step':
+        n = args[4]
+        return '[table slice, %.1f M floats]' % (n / 1e6) if n >= (1 << 20) else '[small tensor]'
+    return ''
 
 
 def kernel_timing(on):

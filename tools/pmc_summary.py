@@ -1,31 +1,101 @@
 #!/usr/bin/env python3
-"""Per-kernel summary of rocprofv3 --pmc counter_collection.csv files (averages over the last launches)."""
+"""Per-entry-point HBM traffic from rocprofv3 --pmc passes (one pass FETCH_SIZE, one pass WRITE_SIZE).
+
+    python tools/pmc_summary.py --steps 4 --out profiles/traffic.json DIR_FETCH DIR_WRITE
+
+Counters are summed over every launch of the kernels behind an entry point and divided by the number of training
+steps of the profiled run (bytes per STEP; bench.py divides by launches per step for the per-launch figure).
+Corrections, as /opt/skills/guides/MI355X_MICROARCH.md "HBM" prescribes: FETCH_SIZE / WRITE_SIZE are in KiB;
+FETCH_SIZE counts wide (16 B/lane) coalesced streaming reads at one half -> doubled for the Adam kernel, whose reads
+are exactly that; WRITE_SIZE is exact for 16 B/lane streaming stores and for float atomics.  The 8-byte random
+gathers of the field kernels are an uncalibrated access width: their FETCH_SIZE is reported uncorrected.
+"""
+import argparse
 import collections
 import csv
 import glob
-import sys
+import json
+import re
 
-KEYS = ['field_fwd_kernel<2, true>', 'field_fwd_kernel<2, false>', 'field_bwd_kernel', 'scatter_kernel', 'adam_kernel',
-        'composite_fwd_kernel', 'composite_bwd_kernel', 'losses_kernel', 'ray_sampling_kernel', 'raygen_kernel']
+ENTRY = [
+    (r'field_fwd_kernel<\d, true, false>', 'nerf_field_fwd'),
+    (r'field_fwd_kernel<\d, false, false>', 'nerf_density_fwd'),
+    (r'field_fwd_kernel<\d, true, true>', 'nerf_field_from_features'),
+    (r'field_fwd_kernel<\d, false, true>', 'nerf_density_from_features'),
+    (r'field_bwd_kernel', 'nerf_field_bwd'),
+    (r'scatter_(small_)?kernel', 'nerf_hashgrid_scatter'),
+    (r'encode_levels_kernel', 'nerf_hashgrid_encode_levels'),
+    (r'adam_kernel', 'nerf_adam_step'),
+    (r'composite_fwd_kernel', 'nerf_composite_fwd'),
+    (r'composite_bwd_kernel', 'nerf_composite_bwd'),
+    (r'losses_kernel', 'nerf_losses'),
+    (r'ray_sampling_kernel', 'nerf_coarse_to_fine'),
+    (r'raygen_kernel', 'nerf_raygen'),
+]
+FETCH_X2 = {'nerf_adam_step'}
 
 
-def main(dirs):
-    for d in dirs:
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--steps', type=int, required=True, help='training steps executed by the profiled command')
+    ap.add_argument('--out', default=None)
+    ap.add_argument('--adam-grid', type=int, default=4194304, help='Grid_Size of the Adam launch on one hashed level')
+    ap.add_argument('--scatter-points', type=int, default=4096 * 128, help='sample points per scatter launch')
+    ap.add_argument('dirs', nargs='+')
+    a = ap.parse_args()
+    tot = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.defaultdict(lambda: collections.defaultdict(int))
+    ns = collections.defaultdict(float)
+    for d in a.dirs:
         for f in glob.glob(d + '/**/*_counter_collection.csv', recursive=True):
-            acc = collections.defaultdict(lambda: collections.defaultdict(list))
             for row in csv.DictReader(open(f)):
-                for k in KEYS:
-                    if k in row['Kernel_Name']:
-                        acc[k][row['Counter_Name']].append((float(row['Counter_Value']),
-                                                            int(row['End_Timestamp']) - int(row['Start_Timestamp'])))
-            print('==', f)
-            for k in KEYS:
-                for c, vals in acc.get(k, {}).items():
-                    big = sorted(vals, key=lambda v: -v[0])[:3] if k == 'adam_kernel' else vals[-3:]
-                    v = sum(x[0] for x in big) / len(big)
-                    t = sum(x[1] for x in big) / len(big)
-                    print('%-30s %-14s launches=%3d  avg=%.5g  avg_ns=%.0f' % (k, c, len(vals), v, t))
+                for pat, entry in ENTRY:
+                    if re.search(pat, row['Kernel_Name']):
+                        c = row['Counter_Name']
+                        tot[entry][c] += float(row['Counter_Value'])
+                        cnt[entry][c] += 1
+                        ns[entry] += (int(row['End_Timestamp']) - int(row['Start_Timestamp'])) / len(a.dirs)
+                        break
+    # per-launch figures for the launch classes bench.py times separately (same names as nerf_amd._lib._launch_class)
+    per_launch = collections.defaultdict(lambda: collections.defaultdict(list))
+    for d in a.dirs:
+        for f in glob.glob(d + '/**/*_counter_collection.csv', recursive=True):
+            for row in csv.DictReader(open(f)):
+                kn, grid = row['Kernel_Name'], int(row['Grid_Size'])
+                cls = None
+                if re.search(r'scatter_kernel<', kn):
+                    cls = ('nerf_hashgrid_scatter[1 hashed level]' if grid == a.scatter_points * 16
+                           else 'nerf_hashgrid_scatter[%d dense levels]' % (grid // (a.scatter_points * 16)))
+                elif re.search(r'adam_kernel', kn) and grid == a.adam_grid:
+                    cls = 'adam_table_slice'
+                if cls:
+                    per_launch[cls][row['Counter_Name']].append(float(row['Counter_Value']) * 1024)
+    pl = {}
+    for cls, c in per_launch.items():
+        fetch = sum(c.get('FETCH_SIZE', [0])) / max(1, len(c.get('FETCH_SIZE', [0])))
+        write = sum(c.get('WRITE_SIZE', [0])) / max(1, len(c.get('WRITE_SIZE', [0])))
+        if cls == 'adam_table_slice':
+            fetch *= 2
+            cls = 'nerf_adam_step[table slice]'      # one hashed level: 2^T entries x F floats
+        pl[cls] = {'hbm_bytes': fetch + write, 'fetch_bytes': fetch, 'write_bytes': write}
+    out = {'per_launch': pl}
+    for entry in tot:
+        fetch = tot[entry].get('FETCH_SIZE', 0.0) * 1024 / a.steps * (2 if entry in FETCH_X2 else 1)
+        write = tot[entry].get('WRITE_SIZE', 0.0) * 1024 / a.steps
+        launches = max(cnt[entry].values()) / a.steps
+        out[entry] = {'hbm_bytes_per_step': fetch + write, 'fetch_bytes_per_step': fetch, 'write_bytes_per_step': write,
+                      'launches_per_step': launches, 'serialized_ms_per_step': ns[entry] / a.steps / 1e6,
+                      'fetch_doubled': entry in FETCH_X2}
+    for k, v in sorted(pl.items()):
+        print('%-52s %8.1f MB/launch (fetch %7.1f, write %7.1f)' % (k, v['hbm_bytes'] / 1e6, v['fetch_bytes'] / 1e6,
+                                                                   v['write_bytes'] / 1e6))
+    for k, v in sorted(((k, v) for k, v in out.items() if k != 'per_launch'), key=lambda kv: -kv[1]['hbm_bytes_per_step']):
+        print('%-28s %8.3f GB/step  (fetch %7.3f, write %7.3f)  %5.1f launches/step  %7.3f ms/step serialized' % (
+            k, v['hbm_bytes_per_step'] / 1e9, v['fetch_bytes_per_step'] / 1e9, v['write_bytes_per_step'] / 1e9,
+            v['launches_per_step'], v['serialized_ms_per_step']))
+    if a.out:
+        json.dump(out, open(a.out, 'w'), indent=1, sort_keys=True)
 
 
 if __name__ == '__main__':
-    main(sys.argv[1:])
+    main()
