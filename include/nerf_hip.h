@@ -163,6 +163,18 @@ int nerf_field_from_features(const NerfGridCfg* grid, const NerfNetCfg* net, con
                              const NerfPointSrc* src, const float* x_hashtable /*[M,L*F]*/, float* sigma, float* rgb,
                              float* xyz /*nullable*/, void* stream);
 
+/* Column map between a row-major [n_rows, n_cols] feature matrix and the flat buffers of the feature all-to-all
+ * (one [n_rows, width_r] block per level owner): element (p, c) lives at flat[offset[c] + p*stride[c]]. */
+#define NERF_MAX_FEATURE_COLS 128
+typedef struct NerfColMap {
+    int64_t offset[NERF_MAX_FEATURE_COLS];
+    int32_t stride[NERF_MAX_FEATURE_COLS];
+} NerfColMap;
+/* direction 0: matrix[p*n_cols + c] = flat[offset[c] + p*stride[c]]   (assemble x_hashtable after the all-to-all)
+ * direction 1: flat[offset[c] + p*stride[c]] = matrix[p*n_cols + c]   (split d(features) before the all-to-all) */
+int nerf_feature_shuffle(const float* src, float* dst, int64_t n_rows, int n_cols, const NerfColMap* map, int direction,
+                         void* stream);
+
 /* ---- hierarchical resampling ---- */
 /* renderer.py:154-160: alpha = 1-exp(-sigma*delta), exclusive transmittance, weights. zlog has
  * row stride zlog_stride (0 = one shared [S] table). */

@@ -35,6 +35,13 @@ class NerfLevelSet(C.Structure):
     _fields_ = [('count', C.c_int32), ('level', C.c_int32 * NERF_MAX_LEVELS)]
 
 
+NERF_MAX_FEATURE_COLS = 128
+
+
+class NerfColMap(C.Structure):
+    _fields_ = [('offset', C.c_int64 * NERF_MAX_FEATURE_COLS), ('stride', C.c_int32 * NERF_MAX_FEATURE_COLS)]
+
+
 _P, _I64, _I, _F = C.c_void_p, C.c_int64, C.c_int, C.c_float
 _G, _N, _S = C.POINTER(NerfGridCfg), C.POINTER(NerfNetCfg), C.POINTER(NerfPointSrc)
 _LS = C.POINTER(NerfLevelSet)
@@ -61,6 +68,7 @@ SIGNATURES = {
     'nerf_hashgrid_scatter_levels': (_I, [_G, _S, _LS, _P, _I64, _P, _P]),
     'nerf_density_from_features': (_I, [_G, _N, _P, _P, _I64, _P, _P]),
     'nerf_field_from_features': (_I, [_G, _N, _P, _P, _P, _I64, _S, _P, _P, _P, _P, _P]),
+    'nerf_feature_shuffle': (_I, [_P, _P, _I64, _I, C.POINTER(NerfColMap), _I, _P]),
     'nerf_coarse_weights': (_I, [_P, _P, _I64, _I64, _I, _P, _P]),
     'nerf_reweight': (_I, [_P, _I64, _I, _F, C.POINTER(C.c_int32), _I, _P, _P]),
     'nerf_sample_pdf': (_I, [_P, _I64, _P, _P, _P, _I64, _I, _I, _P, _P, _P, _P]),

@@ -26,7 +26,7 @@ import torch
 import torch.distributed as dist
 
 from . import parallel
-from ._lib import NerfLevelSet, check, lib, ptr, stream
+from ._lib import NerfColMap, NerfLevelSet, check, lib, ptr, stream
 
 
 def level_costs(cfg):
@@ -111,6 +111,7 @@ class LevelSharding(object):
         for i, c in enumerate(cols):
             inv[c] = i
         self.inv = torch.tensor(inv, device=device, dtype=torch.int64)
+        self._colmaps = {}
         self.dirty = False      # True once an optimizer step made the non-owned levels of the local table stale
 
     # ---- point sources of all ranks -------------------------------------------------------
@@ -134,6 +135,23 @@ class LevelSharding(object):
                    n_points=W * kw['n_points'])
         return out
 
+    def col_map(self, m_local):
+        """NerfColMap of the all-to-all buffers that hold `m_local` rows per rank: level-major column c of the
+        feature matrix sits in the block of the level's owner."""
+        cm = self._colmaps.get(m_local)
+        if cm is None:
+            cm = NerfColMap()
+            base = 0
+            for r, lv in enumerate(self.levels):
+                w = self.width[r]
+                for k, l in enumerate(lv):
+                    for f in range(self.F):
+                        cm.offset[l * self.F + f] = base + k * self.F + f
+                        cm.stride[l * self.F + f] = w
+                base += m_local * w
+            self._colmaps[m_local] = cm
+        return cm
+
     # ---- forward: encode my levels for everybody, all-to-all, assemble [M, L*F] -------------
     def encode_exchange(self, table, src_all, m_local):
         from .nets import make_point_src
@@ -150,7 +168,13 @@ class LevelSharding(object):
         my points, level-major columns)."""
         W, wm = self.world, self.width[self.rank]
         recv = parallel.all_to_all_flat(send, [m_local * wm] * W, [m_local * w for w in self.width])
-        chunks, o = [], 0
+        if recv.is_cuda:        # one pass: owner-major blocks -> [m_local, L*F]
+            LF = self.cfg.n_levels * self.F
+            xh = torch.empty(m_local, LF, device=recv.device, dtype=torch.float32)
+            check(lib().nerf_feature_shuffle(ptr(recv), ptr(xh), m_local, LF, C.byref(self.col_map(m_local)), 0, stream()),
+                  'nerf_feature_shuffle')
+            return xh
+        chunks, o = [], 0       # host tensors (the CPU tests of the exchange logic)
         for w in self.width:
             chunks.append(recv[o:o + m_local * w].view(m_local, w))
             o += m_local * w
@@ -162,8 +186,13 @@ class LevelSharding(object):
         """dfeat [M, L*F] (level-major) -> [world*M, width_mine]: gradient columns of MY levels for the points of
         all ranks."""
         M, W, wm = dfeat.shape[0], self.world, self.width[self.rank]
-        g = dfeat if self.identity else dfeat.index_select(1, self.perm)
-        send = torch.cat([c.reshape(-1) for c in g.split(self.width, 1)])
+        if dfeat.is_cuda:
+            send = torch.empty(dfeat.numel(), device=dfeat.device, dtype=torch.float32)
+            check(lib().nerf_feature_shuffle(ptr(dfeat), ptr(send), M, dfeat.shape[1], C.byref(self.col_map(M)), 1, stream()),
+                  'nerf_feature_shuffle')
+        else:
+            g = dfeat if self.identity else dfeat.index_select(1, self.perm)
+            send = torch.cat([c.reshape(-1) for c in g.split(self.width, 1)])
         recv = parallel.all_to_all_flat(send, [M * w for w in self.width], [M * wm] * W)
         return recv.view(W * M, wm) if wm else recv.view(W * M, 0)
 

@@ -133,3 +133,29 @@ def test_lds_privatised_scatter_matches_global_atomic_path(name):
         check(lib().nerf_hashgrid_bwd(C.byref(cfg), ptr(x01[a:b].contiguous()), ptr(dfeat[a:b].contiguous()), b - a,
                                       ptr(want2), stream()), 'bwd')
     torch.testing.assert_close(got2, want2, rtol=1e-4, atol=2e-5 * float(want2.abs().max()))
+
+
+@pytest.mark.parametrize('world', [2, 3, 8])
+def test_feature_shuffle_matches_torch_permutation(world):
+    """nerf_feature_shuffle (one pass) == the cat / index_select / split it replaces, in both directions."""
+    from nerf_amd._lib import check, lib, ptr, stream
+    from nerf_amd.level_parallel import LevelSharding
+    net, _ = _make_pair(NET_CFGS['base19'])
+    cfg = net.encoder.cfg
+    LF, M = cfg.n_levels * cfg.n_features, 777
+    for rank in (0, world - 1):
+        sh = LevelSharding(cfg, 'cuda', rank=rank, world=world)
+        recv = torch.randn(M * LF, device='cuda')
+        chunks, o = [], 0
+        for w in sh.width:
+            chunks.append(recv[o:o + M * w].view(M, w))
+            o += M * w
+        want = torch.cat(chunks, 1).index_select(1, sh.inv)
+        got = torch.empty(M, LF, device='cuda')
+        check(lib().nerf_feature_shuffle(ptr(recv), ptr(got), M, LF, C.byref(sh.col_map(M)), 0, stream()), 'shuffle')
+        assert torch.equal(got, want)
+        back = torch.empty(M * LF, device='cuda')
+        check(lib().nerf_feature_shuffle(ptr(got), ptr(back), M, LF, C.byref(sh.col_map(M)), 1, stream()), 'shuffle')
+        assert torch.equal(back, recv)
+        want_send = torch.cat([c.reshape(-1) for c in got.index_select(1, sh.perm).split(sh.width, 1)])
+        assert torch.equal(back, want_send)

@@ -104,9 +104,11 @@ def main():
         t['adam'] = timed(adam)
         # assemble / split passes (torch): xh = cat(...).index_select ; dfeat.index_select -> split -> cat
         xh_parts = [torch.empty(N * Sf, w, device='cuda') for w in sh.width]
-        t['assemble_fine'] = timed(lambda: torch.cat(xh_parts, 1).index_select(1, sh.inv))
+        recv_flat = torch.randn(N * Sf * LF, device="cuda")
+        xh_out = torch.empty(N * Sf, LF, device="cuda")
+        t["assemble_fine"] = timed(lambda: check(lib().nerf_feature_shuffle(ptr(recv_flat), ptr(xh_out), N * Sf, LF, C.byref(sh.col_map(N * Sf)), 0, stream()), "sh"))
         dfeat = torch.randn(N * Sf, LF, device='cuda')
-        t['split_dfeat'] = timed(lambda: torch.cat([c.reshape(-1) for c in dfeat.index_select(1, sh.perm).split(sh.width, 1)]))
+        t["split_dfeat"] = timed(lambda: check(lib().nerf_feature_shuffle(ptr(dfeat), ptr(recv_flat), N * Sf, LF, C.byref(sh.col_map(N * Sf)), 1, stream()), "sh"))
         t = {k: round(x, 4) for k, x in t.items()}
         t['levels'] = sh.mine
         t['total_table_ms'] = round(sum(x for k, x in t.items() if k != 'levels'), 4)
