@@ -152,72 +152,135 @@ class LevelSharding(object):
             self._colmaps[m_local] = cm
         return cm
 
+    # ---- helpers ---------------------------------------------------------------------------
+    def _sub_src(self, src_all, a, b, m_local):
+        """make_point_src kwargs for the points of ranks [a, b) out of the gathered source."""
+        kw = dict(outer_bound=src_all['outer_bound'], inner_bound=src_all.get('inner_bound', 0.0))
+        if src_all.get('x') is not None:
+            kw.update(x=src_all['x'][a * m_local:b * m_local], n_points=(b - a) * m_local)
+            return kw
+        S, zs = src_all['n_samples'], src_all['z_stride']
+        R = m_local // S
+        z = src_all['z'] if zs == 0 else src_all['z'][a * R:b * R]
+        kw.update(rays_o=src_all['rays_o'][a * R:b * R], rays_d=src_all['rays_d'][a * R:b * R], z=z, z_stride=zs,
+                  n_samples=S, n_points=(b - a) * m_local)
+        return kw
+
+    def _blocks(self, flat, m_local, widths):
+        out, o = [], 0
+        for w in widths:
+            out.append(flat[o:o + m_local * w])
+            o += m_local * w
+        return out
+
+    def _encode(self, table, kw, out, stride):
+        from .nets import make_point_src
+        src = make_point_src(**kw)
+        check(lib().nerf_hashgrid_encode_levels(C.byref(self.cfg), ptr(table), C.byref(src), C.byref(self.my_set), ptr(out),
+                                                stride, stream()), 'nerf_hashgrid_encode_levels')
+
     # ---- forward: encode my levels for everybody, all-to-all, assemble [M, L*F] -------------
     def encode_exchange(self, table, src_all, m_local):
-        from .nets import make_point_src
-        W, wm = self.world, self.width[self.rank]
-        src = make_point_src(**src_all)
-        send = torch.empty(W * m_local, max(wm, 1), device=table.device, dtype=torch.float32)
+        """x_hashtable [m_local, L*F] of this rank's points.  Order of work: encode my levels for the points of the
+        OTHER ranks, start the all-to-all, encode them for my own points (straight into my block of the receive
+        buffer) while the exchange is in flight, wait, one shuffle pass into level-major rows."""
+        W, r, wm = self.world, self.rank, self.width[self.rank]
+        dev = table.device
+        send = torch.empty(W * m_local * wm, device=dev, dtype=torch.float32)
+        recv = torch.empty(m_local * sum(self.width), device=dev, dtype=torch.float32)
+        send_blocks = self._blocks(send, m_local, [wm] * W)
+        recv_blocks = self._blocks(recv, m_local, self.width)
         if wm:
-            check(lib().nerf_hashgrid_encode_levels(C.byref(self.cfg), ptr(table), C.byref(src), C.byref(self.my_set),
-                                                    ptr(send), wm, stream()), 'nerf_hashgrid_encode_levels')
-        return self.exchange_features(send.view(-1)[:W * m_local * wm], m_local)
+            for (a, b) in ((0, r), (r + 1, W)):
+                if b > a:
+                    self._encode(table, self._sub_src(src_all, a, b, m_local), send_blocks[a], wm)
+        work = parallel.all_to_all_blocks(recv_blocks, send_blocks, async_op=True)
+        if wm:
+            self._encode(table, self._sub_src(src_all, r, r + 1, m_local), recv_blocks[r], wm)
+        if work is not None:
+            work.wait()
+        return self.assemble(recv, m_local)
 
-    def exchange_features(self, send, m_local):
-        """send: flat [world, m_local, width_mine] (my levels, everybody's points) -> xh [m_local, L*F] (all levels,
-        my points, level-major columns)."""
-        W, wm = self.world, self.width[self.rank]
-        recv = parallel.all_to_all_flat(send, [m_local * wm] * W, [m_local * w for w in self.width])
-        if recv.is_cuda:        # one pass: owner-major blocks -> [m_local, L*F]
+    def assemble(self, recv, m_local):
+        """Owner-major blocks of the receive buffer -> [m_local, L*F] level-major rows."""
+        if recv.is_cuda:
             LF = self.cfg.n_levels * self.F
             xh = torch.empty(m_local, LF, device=recv.device, dtype=torch.float32)
             check(lib().nerf_feature_shuffle(ptr(recv), ptr(xh), m_local, LF, C.byref(self.col_map(m_local)), 0, stream()),
                   'nerf_feature_shuffle')
             return xh
-        chunks, o = [], 0       # host tensors (the CPU tests of the exchange logic)
-        for w in self.width:
-            chunks.append(recv[o:o + m_local * w].view(m_local, w))
-            o += m_local * w
-        xh = torch.cat(chunks, 1)
+        chunks = [blk.view(m_local, w) for blk, w in zip(self._blocks(recv, m_local, self.width), self.width)]
+        xh = torch.cat(chunks, 1)       # host tensors (the CPU tests of the exchange logic)
         return xh if self.identity else xh.index_select(1, self.inv)
 
+    def exchange_features(self, send, m_local):
+        """send: flat [world, m_local, width_mine] (my levels, everybody's points, own block included) ->
+        xh [m_local, L*F].  The plain form of encode_exchange's data movement (used by the CPU tests)."""
+        W, r, wm = self.world, self.rank, self.width[self.rank]
+        recv = torch.empty(m_local * sum(self.width), device=send.device, dtype=send.dtype)
+        send_blocks, recv_blocks = self._blocks(send, m_local, [wm] * W), self._blocks(recv, m_local, self.width)
+        parallel.all_to_all_blocks(recv_blocks, send_blocks)
+        recv_blocks[r].copy_(send_blocks[r])
+        return self.assemble(recv, m_local)
+
     # ---- backward: d(features) back to the level owners ------------------------------------
-    def exchange_dfeat(self, dfeat):
-        """dfeat [M, L*F] (level-major) -> [world*M, width_mine]: gradient columns of MY levels for the points of
-        all ranks."""
-        M, W, wm = dfeat.shape[0], self.world, self.width[self.rank]
+    def split(self, dfeat):
+        """[M, L*F] level-major rows -> flat owner-major blocks ([M, width_r] for every owner r)."""
+        M = dfeat.shape[0]
         if dfeat.is_cuda:
             send = torch.empty(dfeat.numel(), device=dfeat.device, dtype=torch.float32)
             check(lib().nerf_feature_shuffle(ptr(dfeat), ptr(send), M, dfeat.shape[1], C.byref(self.col_map(M)), 1, stream()),
                   'nerf_feature_shuffle')
-        else:
-            g = dfeat if self.identity else dfeat.index_select(1, self.perm)
-            send = torch.cat([c.reshape(-1) for c in g.split(self.width, 1)])
-        recv = parallel.all_to_all_flat(send, [M * w for w in self.width], [M * wm] * W)
-        return recv.view(W * M, wm) if wm else recv.view(W * M, 0)
+            return send
+        g = dfeat if self.identity else dfeat.index_select(1, self.perm)
+        return torch.cat([c.reshape(-1) for c in g.split(self.width, 1)])
 
-    def scatter(self, src_all, dfeat_mine, dtable, pipe=None):
-        """dtable[my levels] += scatter(dfeat_mine); with a TablePipeline, level by level with an event after each."""
+    def exchange_dfeat(self, dfeat):
+        """dfeat [M, L*F] (level-major) -> [world*M, width_mine]: gradient columns of MY levels for the points of
+        all ranks (own block included).  The plain form of exchange_scatter's data movement."""
+        M, W, r, wm = dfeat.shape[0], self.world, self.rank, self.width[self.rank]
+        send = self.split(dfeat)
+        recv = torch.empty(W * M * wm, device=dfeat.device, dtype=dfeat.dtype)
+        send_blocks, recv_blocks = self._blocks(send, M, self.width), self._blocks(recv, M, [wm] * W)
+        parallel.all_to_all_blocks(recv_blocks, send_blocks)
+        recv_blocks[r].copy_(send_blocks[r])
+        return recv.view(W * M, wm)
+
+    def _scatter(self, kw, levels, dfeat_ptr, stride, dtable):
         from .nets import make_point_src
-        wm = self.width[self.rank]
+        src = make_point_src(**kw)
+        check(lib().nerf_hashgrid_scatter_levels(C.byref(self.cfg), C.byref(src), C.byref(levels), dfeat_ptr, stride,
+                                                 ptr(dtable), stream()), 'nerf_hashgrid_scatter_levels')
+
+    def exchange_scatter(self, dfeat, src_all, dtable, pipe=None):
+        """dtable[my levels] += scatter of d(features) from the points of all ranks.  The gradient rows of my own
+        points are scattered while the all-to-all that brings the other ranks' rows is in flight; with a
+        TablePipeline the remote part then goes level by level with an event after each (Adam follows on the side
+        stream)."""
+        M, W, r, wm = dfeat.shape[0], self.world, self.rank, self.width[self.rank]
+        send = self.split(dfeat)
+        recv = torch.empty(W * M * wm, device=dfeat.device, dtype=torch.float32)
+        send_blocks, recv_blocks = self._blocks(send, M, self.width), self._blocks(recv, M, [wm] * W)
+        work = parallel.all_to_all_blocks(recv_blocks, send_blocks, async_op=True)
+        if pipe is not None:
+            pipe.begin(dtable)
+        if wm:
+            self._scatter(self._sub_src(src_all, r, r + 1, M), self.my_set, ptr(send_blocks[r]), wm, dtable)
+        if work is not None:
+            work.wait()
         if not wm:
-            if pipe is not None:
-                pipe.begin(dtable)
             return
-        src = make_point_src(**src_all)
+        remote = [(a, b) for (a, b) in ((0, r), (r + 1, W)) if b > a]
         if pipe is None:
-            check(lib().nerf_hashgrid_scatter_levels(C.byref(self.cfg), C.byref(src), C.byref(self.my_set), ptr(dfeat_mine),
-                                                     wm, ptr(dtable), stream()), 'nerf_hashgrid_scatter_levels')
+            for (a, b) in remote:
+                self._scatter(self._sub_src(src_all, a, b, M), self.my_set, ptr(recv_blocks[a]), wm, dtable)
             return
-        pipe.begin(dtable)
         slot = {l: i for i, l in enumerate(self.mine)}
-        base = ptr(dfeat_mine)
         for (l0, cnt) in pipe.groups:
             for l in range(l0, l0 + cnt):
                 one = _level_set([l])
-                check(lib().nerf_hashgrid_scatter_levels(C.byref(self.cfg), C.byref(src), C.byref(one),
-                                                         base + 4 * slot[l] * self.F, wm, ptr(dtable), stream()),
-                      'nerf_hashgrid_scatter_levels')
+                for (a, b) in remote:
+                    self._scatter(self._sub_src(src_all, a, b, M), one, ptr(recv_blocks[a]) + 4 * slot[l] * self.F, wm, dtable)
             pipe.level_done(l0, cnt)
 
     # ---- table consistency ---------------------------------------------------------------

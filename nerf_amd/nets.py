@@ -220,8 +220,7 @@ class _ShardedFieldFn(torch.autograd.Function):
         check(lib().nerf_field_bwd(C.byref(net.encoder.cfg), C.byref(net.net_cfg), None, ptr(sigma_w), ptr(color_w),
                                    ptr(latent), net.N, C.byref(src), ptr(xh), ptr(f32(dsigma)), ptr(f32(drgb)),
                                    ptr(dfeat), None, ptr(dsw), ptr(dcw), ptr(dlat), stream()), 'nerf_field_bwd')
-        dmine = sh.exchange_dfeat(dfeat)
-        sh.scatter(ctx.src_all, dmine, dtable, net.table_pipeline)
+        sh.exchange_scatter(dfeat, ctx.src_all, dtable, net.table_pipeline)
         if direct:
             return None, None, None, None, None, None, None
         return dtable, dsw, dcw, dlat, None, None, None

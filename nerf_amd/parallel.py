@@ -75,8 +75,19 @@ def all_reduce_grads(params, async_op=False, skip=()):
         return []
     handles = []
     skip_ids = {id(p) for p in skip}
-    for p in sorted((p for p in params if p is not None and p.grad is not None and id(p) not in skip_ids),
-                    key=lambda t: -t.numel()):
+    todo = sorted((p for p in params if p is not None and p.grad is not None and id(p) not in skip_ids),
+                  key=lambda t: -t.numel())
+    small = [p for p in todo if p.numel() <= (1 << 20)]
+    if len(small) > 1 and not async_op:
+        # the MLP / latent gradients are a few KB each: one collective for all of them
+        flat = torch.cat([p.grad.reshape(-1) for p in small])
+        all_reduce_sum_(flat)
+        o = 0
+        for p in small:
+            p.grad.copy_(flat[o:o + p.numel()].view_as(p.grad))
+            o += p.numel()
+        todo = [p for p in todo if p.numel() > (1 << 20)]
+    for p in todo:
         h = all_reduce_sum_(p.grad, async_op=async_op)
         if async_op and h is not None:
             handles.append(h)
@@ -157,6 +168,30 @@ def all_to_all_flat(send, send_splits, recv_splits):
     out = send.new_empty(sum(recv_splits))
     dist.all_to_all_single(out, send, list(recv_splits), list(send_splits))
     return out
+
+
+def all_to_all_blocks(recv_blocks, send_blocks, async_op=False):
+    """send_blocks[r] -> rank r, recv_blocks[r] <- rank r (flat, contiguous views; sizes must match pairwise).
+    The caller's OWN block is not transferred -- callers fill / consume it locally while the exchange is in flight.
+    Returns a work handle when async_op and the backend is asynchronous (RCCL), else None."""
+    me, world = rank(), world_size()
+    if dist.get_backend() == 'gloo':       # no list all-to-all in gloo: one flat exchange of host tensors
+        ins = [b.reshape(-1).cpu() for i, b in enumerate(send_blocks) if i != me]
+        out_sizes = [b.numel() if i != me else 0 for i, b in enumerate(recv_blocks)]
+        in_sizes = [b.numel() if i != me else 0 for i, b in enumerate(send_blocks)]
+        out = torch.empty(sum(out_sizes), dtype=send_blocks[0].dtype)
+        dist.all_to_all_single(out, torch.cat(ins) if ins else out.new_empty(0), out_sizes, in_sizes)
+        o = 0
+        for i, b in enumerate(recv_blocks):
+            if i != me:
+                b.reshape(-1).copy_(out[o:o + b.numel()])
+                o += b.numel()
+        return None
+    empty = send_blocks[0].new_empty(0)
+    outs = [b.reshape(-1) if i != me else empty for i, b in enumerate(recv_blocks)]
+    ins = [b.reshape(-1) if i != me else empty for i, b in enumerate(send_blocks)]
+    work = dist.all_to_all(outs, ins, async_op=async_op)
+    return work if async_op else None
 
 
 def broadcast_(t, src):
