@@ -121,6 +121,19 @@ class FullyFusedMLP(nn.Module):
         return out.reshape(*x.shape[:-1], self.n_output_dims)
 
 
+def _slice_src_kwargs(kw, a, b, unit):
+    """make_point_src kwargs restricted to rays [a, b) (mode 1) or points [a, b) (mode 0, unit = 1)."""
+    out = dict(kw)
+    if kw.get('x') is not None:
+        out.update(x=kw['x'][a:b], d=kw['d'][a:b] if kw.get('d') is not None else None,
+                   n=kw['n'][a:b] if kw.get('n') is not None else None, n_points=b - a)
+        return out
+    zs = kw.get('z_stride', 0)
+    out.update(rays_o=kw['rays_o'][a:b], rays_d=kw['rays_d'][a:b], z=kw['z'] if zs == 0 else kw['z'][a:b],
+               n=kw['n'][a:b] if kw.get('n') is not None else None, n_points=(b - a) * unit)
+    return out
+
+
 class _FieldFn(torch.autograd.Function):
     """sigma, rgb = field(points); backward = nerf_field_bwd (gradients for table, MLPs, latent)."""
 
@@ -165,10 +178,41 @@ class _FieldFn(torch.autograd.Function):
             dtable, dsw, dcw = torch.zeros_like(table), torch.zeros_like(sigma_w), torch.zeros_like(color_w)
             dlat = torch.zeros_like(latent) if latent is not None else None
         dfeat = torch.empty_like(xh)
-        check(lib().nerf_field_bwd(C.byref(net.encoder.cfg), C.byref(net.net_cfg), ptr(table), ptr(sigma_w), ptr(color_w),
-                                   ptr(latent), net.N, C.byref(src), ptr(xh), ptr(f32(dsigma)), ptr(f32(drgb)),
-                                   ptr(dfeat), None, ptr(dsw), ptr(dcw), ptr(dlat), stream()), 'nerf_field_bwd')
-        net.scatter_table(src, dfeat, dtable)
+        dsigma, drgb = f32(dsigma), f32(drgb)
+        pipe = net.table_pipeline
+        unit = src.n_samples if src.mode == 1 else 1            # points per ray (chunks are cut between rays)
+        rows = src.n_points // unit
+        cut = int(rows * pipe.early_fraction) if pipe is not None else 0
+        if pipe is None or not direct or cut * unit < 65536 or (rows - cut) * unit < 65536:
+            check(lib().nerf_field_bwd(C.byref(net.encoder.cfg), C.byref(net.net_cfg), ptr(table), ptr(sigma_w), ptr(color_w),
+                                       ptr(latent), net.N, C.byref(src), ptr(xh), ptr(dsigma), ptr(drgb),
+                                       ptr(dfeat), None, ptr(dsw), ptr(dcw), ptr(dlat), stream()), 'nerf_field_bwd')
+            net.scatter_table(src, dfeat, dtable)
+        else:
+            # Two chunks of rays: the table scatter of the first (bound by memory-side atomics) runs on its own
+            # stream underneath the MLP backward of the second (bound by the matrix cores).
+            pipe.begin(dtable)
+            pipe.keep = [dfeat, dsigma, drgb, xh]
+            if pipe.scatter_stream is None:
+                pipe.scatter_stream = torch.cuda.Stream()
+            main = torch.cuda.current_stream()
+            for k, (a, b) in enumerate(((0, cut), (cut, rows))):
+                kw = _slice_src_kwargs(ctx.src_kwargs, a, b, unit)
+                sub = make_point_src(**kw)
+                pa, pb = a * unit, b * unit
+                check(lib().nerf_field_bwd(C.byref(net.encoder.cfg), C.byref(net.net_cfg), None, ptr(sigma_w), ptr(color_w),
+                                           ptr(latent), net.N, C.byref(sub), ptr(xh[pa:pb]), ptr(dsigma[pa:pb]),
+                                           ptr(drgb[pa:pb]), ptr(dfeat[pa:pb]), None, ptr(dsw), ptr(dcw), ptr(dlat),
+                                           stream()), 'nerf_field_bwd')
+                if k == 0:
+                    done = torch.cuda.Event()
+                    done.record(main)
+                    with torch.cuda.stream(pipe.scatter_stream):
+                        pipe.scatter_stream.wait_event(done)
+                        net.scatter_levels_pipelined(sub, dfeat[pa:pb], dtable, final=False)
+                else:
+                    net.scatter_levels_pipelined(sub, dfeat[pa:pb], dtable, final=True)
+                pipe.keep.append(kw)
         if direct:
             return None, None, None, None, None, None, None
         return dtable, dsw, dcw, dlat, None, None, None
@@ -293,10 +337,19 @@ class NeRFNetwork(nn.Module):
                   'nerf_hashgrid_scatter')
             return
         pipe.begin(dtable)
+        self.scatter_levels_pipelined(src, dfeat, dtable, final=True)
+
+    def scatter_levels_pipelined(self, src, dfeat, dtable, final):
+        """One pass over the pipeline's level groups on the current stream; `final` marks the last part of the
+        step's scatter (its events release the all-reduce / Adam of each group)."""
+        cfg, pipe = self.encoder.cfg, self.table_pipeline
         for (l0, cnt) in pipe.groups:
             check(lib().nerf_hashgrid_scatter(C.byref(cfg), C.byref(src), ptr(dfeat), ptr(dtable), l0, cnt, stream()),
                   'nerf_hashgrid_scatter')
-            pipe.level_done(l0, cnt)
+            if final:
+                pipe.level_done(l0, cnt)
+            else:
+                pipe.level_partial(l0)
 
     # ---- level-sharded table ----------------------------------------------------------------
     def shard_levels(self, owner=None):

@@ -23,10 +23,17 @@ class TablePipeline(object):
         gradient is complete without any all-reduce: pass reduce=False)."""
         L = grid_cfg.n_levels
         if levels is None:
-            groups = [(l, 1) for l in range(L) if grid_cfg.hashed[l]]
+            hashed = [(l, 1) for l in range(L) if grid_cfg.hashed[l]]
             dense = [l for l in range(L) if not grid_cfg.hashed[l]]
-            if dense:   # the dense pyramid is small: one group, last
-                groups.append((dense[0], len(dense)))
+            # the small dense levels (LDS-privatised scatter, tiny Adam slices) travel as one group; the big dense
+            # levels are groups of their own
+            small = [l for l in dense if grid_cfg.entries[l] * n_features <= 16 * 32768]
+            big = [(l, 1) for l in reversed(dense) if l not in small]
+            small = [(small[0], len(small))] if small and small == list(range(small[0], small[0] + len(small))) else \
+                    [(l, 1) for l in small]
+            order = os.environ.get('NERF_PIPE_ORDER', 'A')
+            groups = {'A': hashed + big + small, 'B': small + big + hashed, 'C': small + hashed + big,
+                      'D': big + hashed + small}[order]
         else:       # owned levels are not contiguous: one group each, big hashed levels first
             groups = [(l, 1) for l in sorted(levels, key=lambda l: (-int(grid_cfg.entries[l]), l))]
         self.groups = groups
@@ -37,18 +44,33 @@ class TablePipeline(object):
             b = (int(grid_cfg.offset[l0 + cnt]) if l0 + cnt < L else int(grid_cfg.total_entries)) * n_features
             self.slices[l0] = (a, b)
         self.events = {}
+        self.early_events = {}
         self.works = {}
         self.side = None
+        self.scatter_stream = None      # carries the scatter of the first backward chunk (see _FieldFn.backward)
+        self.early_fraction = float(os.environ.get('NERF_BWD_SPLIT', '0.35'))
         self.pending = False
         self.dtable = None
+        self.keep = []
 
     def begin(self, dtable):
         self.dtable = dtable
         self.pending = True
         self.works = {}
+        self.early_events = {}
+        self.keep = []
+
+    def level_partial(self, l0):
+        """A first part of the level group's scatter has been issued on the CURRENT stream (atomics commute, so
+        the parts may run concurrently); Adam on the group waits for this event too."""
+        ev = torch.cuda.Event()
+        ev.record()
+        self.early_events.setdefault(l0, []).append(ev)
 
     def level_done(self, l0, cnt):
         if self.reduce and dist.is_initialized() and dist.get_world_size() > 1:
+            for ev in self.early_events.get(l0, ()):     # the slice must be complete before it is reduced
+                torch.cuda.current_stream().wait_event(ev)
             a, b = self.slices[l0]
             self.works[l0] = parallel.all_reduce_sum_(self.dtable[a:b], async_op=True)
         ev = self.events.get(l0)
@@ -146,6 +168,8 @@ class FusedAdam(torch.optim.Optimizer):
             for (l0, cnt) in pipe.groups:
                 a, b = pipe.slices[l0]
                 pipe.side.wait_event(pipe.events[l0])
+                for ev in pipe.early_events.get(l0, ()):
+                    pipe.side.wait_event(ev)
                 w = pipe.works.get(l0)
                 if w is not None:
                     w.wait()                      # side stream waits for the slice's all-reduce

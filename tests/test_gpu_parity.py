@@ -344,3 +344,44 @@ def test_extract_dense_geometry_vs_oracle():
     assert (kg & ks) == (ko & ks) and len(ko) > 0
     if pts_g.shape == pts_o.shape and torch.equal(pts_g, pts_o):
         torch.testing.assert_close(col_g, col_o, rtol=0, atol=1e-5)
+
+
+def test_chunked_backward_matches_unchunked():
+    """Batches of >= 187 k points split the backward into two ray chunks whose table scatters run on two streams
+    (nets._FieldFn.backward); the trained parameters must equal the single-chunk path up to atomic ordering."""
+    from nerf_amd import helpers
+    from nerf_amd.optim import FusedAdam
+    from nerf_amd.renderer import NerfRenderer
+
+    def run(split):
+        net, _ = _make_pair(NET_CFGS['small'])
+        R = NerfRenderer(net, 2, 2.5, [1.6, 4.8], [64], 128, 0.2)
+        opt = FusedAdam([{'params': list(net.encoder.parameters()) + [net.latent_emb], 'lr': 2e-2},
+                         {'params': list(net.sigma_net.parameters()) + list(net.color_net.parameters()), 'lr': 1e-3}],
+                        betas=(0.9, 0.99), eps=1e-15).attach(net)
+        net.table_pipeline.early_fraction = split
+        n, h, w, K, E, bg, noise, gt = [t.cuda() for t in _batch(2, 1600)]
+        grads = None
+        for it in range(2):
+            opt.zero_grad()
+            img, wts, zs, _ = R.render(n, h, w, K, E, bg, noise=noise)
+            loss, _ = helpers.fused_train_loss(img, gt, wts, zs, 1e-3, 1e-1)
+            loss.backward()
+            used_chunks = bool(net.table_pipeline.early_events)
+            if it == 0:
+                torch.cuda.synchronize()        # both scatter streams
+                grads = [p.grad.detach().clone() for p in (net.encoder.params, net.sigma_net.params, net.color_net.params,
+                                                           net.latent_emb)]
+            opt.step()
+        torch.cuda.synchronize()
+        return used_chunks, grads, [p.detach().clone() for p in (net.encoder.params, net.sigma_net.params,
+                                                                  net.color_net.params, net.latent_emb)]
+    c0, g_want, want = run(0.0)
+    c1, g_got, got = run(0.35)
+    assert not c0 and c1
+    for g, w, name in zip(g_got, g_want, ('table', 'sigma_net', 'color_net', 'latent')):     # gradients: summation order only
+        torch.testing.assert_close(g, w, rtol=1e-4, atol=1e-5 * float(w.abs().max()), msg=lambda m, n=name: n + ': ' + m)
+    for g, w, name in zip(got, want, ('table', 'sigma_net', 'color_net', 'latent')):
+        # Adam divides by sqrt(v): entries whose gradient is ~0 amplify summation-order noise to +-lr
+        torch.testing.assert_close(g, w, rtol=0, atol=2e-3 * 40, msg=lambda m, n=name: n + ': ' + m)
+        assert float(((g - w).abs() > 1e-4).float().mean()) < 0.02, name
