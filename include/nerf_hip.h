@@ -202,7 +202,8 @@ int nerf_composite_bwd(const float* sigma, const float* rgb, const float* zlog, 
                        const float* dweights, int64_t n_rays, int n_samples, float* dsigma, float* drgb, void* stream);
 
 /* ---- losses: helpers.py:21-32, trainer.py:153-169 ---- */
-/* sums[0..3] (double, zeroed by the call) receive loss_rgb, loss_dist, loss_depth, mse.
+/* sums[0..4] (double, zeroed by the call) receive loss_rgb, loss_dist, loss_depth, mse and
+ * loss_rgb + lam_dist*loss_dist + lam_depth*loss_depth.
  * dimage / dweights (nullable) receive grad_scale * d(loss_rgb + lam_dist*loss_dist + lam_depth*loss_depth).
  * sorted != 0 asserts zlog_s rows are non-decreasing (O(S) distortion form), else O(S^2). */
 int nerf_losses(const float* image, const float* gt, const float* weights, const float* zlog_s, int64_t n_rays,

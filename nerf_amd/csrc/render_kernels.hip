@@ -568,6 +568,10 @@ __global__ __launch_bounds__(256) void losses_kernel(const float* __restrict__ i
     if (threadIdx.x < 4) {
         double v = s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
         atomicAdd(&sums[threadIdx.x], v);
+    } else if (threadIdx.x == 4) {   // the training loss itself (trainer.py:168), so that the host needs no arithmetic
+        double v = 0;
+        for (int k = 0; k < 4; ++k) v += s_part[k][0] + (double)lam_dist * s_part[k][1] + (double)lam_depth * s_part[k][2];
+        atomicAdd(&sums[4], v);
     }
 }
 
@@ -747,7 +751,7 @@ int nerf_losses(const float* image, const float* gt, const float* weights, const
     NERF_REQUIRE((weights == nullptr) == (zlog_s == nullptr), "weights and zlog_s go together");
     NERF_REQUIRE(check_ray_args(n_rays, n_samples) != 2, "n_samples must be in [1, 512]");
     NERF_REQUIRE(n_rays > 0, "need at least one ray");
-    zero_doubles_kernel<<<1, 64, 0, S_(stream)>>>(sums, 4);
+    zero_doubles_kernel<<<1, 64, 0, S_(stream)>>>(sums, 5);
     losses_kernel<<<(unsigned)ceil_div64(n_rays, kRaysPerBlock), 256, 0, S_(stream)>>>(
         image, gt, weights, zlog_s, n_rays, n_samples, lam_dist, lam_depth, grad_scale, sorted, sums, dimage, dweights);
     return nerf_launch_status("nerf_losses");

@@ -19,7 +19,7 @@ class _LossFn(torch.autograd.Function):
         w = f32(weights) if use_w else None
         s = f32(zlog_s) if use_w else None
         S = w.shape[1] if use_w else 1
-        sums = torch.empty(4, device=img.device, dtype=torch.float64)
+        sums = torch.empty(5, device=img.device, dtype=torch.float64)
         dimage = torch.empty_like(img)
         dweights = torch.empty_like(w) if use_w else None
         check(lib().nerf_losses(ptr(img), ptr(g), ptr(w), ptr(s), N, S, lam_dist, lam_depth, 1.0, 1 if sorted_s else 0,
@@ -27,17 +27,18 @@ class _LossFn(torch.autograd.Function):
         ctx.save_for_backward(dimage, dweights)
         ctx.use_w = use_w
         ctx.want = want
-        parts = sums.to(torch.float32)
-        if want == 'total':
-            out = parts[0] + lam_dist * parts[1] + lam_depth * parts[2]
-        else:
-            out = parts[{'rgb': 0, 'dist': 1, 'depth': 2, 'mse': 3}[want]]
+        both = sums.to(torch.float32)
+        parts = both[:4]
+        out = both[{'rgb': 0, 'dist': 1, 'depth': 2, 'mse': 3, 'total': 4}[want]]
         ctx.mark_non_differentiable(parts)
+        ctx.set_materialize_grads(False)
         return out, parts
 
     @staticmethod
     def backward(ctx, dout, _dparts):
         dimage, dweights = ctx.saved_tensors
+        if dout is None:
+            return None, None, None, None, None, None, None, None
         gi = dimage * dout
         gw = dweights * dout if ctx.use_w else None
         return gi, None, gw, None, None, None, None, None

@@ -72,15 +72,26 @@ class ProceduralSceneLoader(object):
         """camera_geometry_loader.py:91-108."""
         n, h, w = n.to(self.device), h.to(self.device), w.to(self.device)
         K = self.intrinsics[n]
-        E = self.extrinsics[n].clone()
-        E[..., :3, 3] = E[..., :3, 3] - self.translation_center
+        E = self._centred_extrinsics()[n]
         if self.images is not None:
             rgb_gt, color_bg = self.format_groundtruth(self.images[n, h, w, :], background)
         else:   # no rendered ground truth: deterministic pseudo-colours (throughput runs)
             color_bg = (torch.rand(3, device=self.device, generator=self.generator) if background is None
                         else torch.tensor(background, dtype=torch.float32, device=self.device))
-            rgb_gt = torch.stack([(h % 256), (w % 256), ((h + w) % 256)], -1).to(torch.float32) / 255
+            hw = torch.stack([h, w, h + w], -1)
+            rgb_gt = (hw % 256).to(torch.float32) / 255
         return n, h, w, K, E, rgb_gt, color_bg, None
+
+    def _centred_extrinsics(self):
+        """extrinsics with translation_center subtracted (camera_geometry_loader.py:95), cached per version of the
+        two tensors so that a batch costs one gather instead of gather + clone + subtract + copy."""
+        key = (self.extrinsics.data_ptr(), self.extrinsics._version, self.translation_center.data_ptr(),
+               self.translation_center._version)
+        if getattr(self, '_ec_key', None) != key:
+            E = self.extrinsics.clone()
+            E[..., :3, 3] = E[..., :3, 3] - self.translation_center
+            self._ec, self._ec_key = E, key
+        return self._ec
 
     def get_random_batch(self, batch_size, device='cuda'):
         """camera_geometry_loader.py:112-117, sampled on the GPU."""
@@ -108,6 +119,4 @@ class ProceduralSceneLoader(object):
 
     def get_calibration(self, device='cuda'):
         """camera_geometry_loader.py:146-152."""
-        E = self.extrinsics.clone()
-        E[..., :3, 3] = E[..., :3, 3] - self.translation_center
-        return self.N, self.H, self.W, self.intrinsics, E
+        return self.N, self.H, self.W, self.intrinsics, self._centred_extrinsics().clone()

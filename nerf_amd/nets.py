@@ -153,6 +153,7 @@ class _FieldFn(torch.autograd.Function):
         ctx.net, ctx.src_kwargs = net, src_kwargs
         ctx.save_for_backward(table, sigma_w, color_w, latent, xh)
         ctx.mark_non_differentiable(xh)
+        ctx.set_materialize_grads(False)
         if xyz is not None:
             ctx.mark_non_differentiable(xyz)
             return sigma, rgb, xh, xyz
@@ -239,6 +240,7 @@ class _ShardedFieldFn(torch.autograd.Function):
         ctx.net, ctx.src_kwargs, ctx.src_all = net, src_kwargs, src_all
         ctx.save_for_backward(table, sigma_w, color_w, latent, xh)
         ctx.mark_non_differentiable(xh)
+        ctx.set_materialize_grads(False)
         if xyz is not None:
             ctx.mark_non_differentiable(xyz)
         return sigma, rgb, xh, xyz

@@ -36,12 +36,15 @@ class _CompositeFn(torch.autograd.Function):
                                        ptr(invdepth), ptr(weights), ptr(zlog_s), stream()), 'nerf_composite_fwd')
         ctx.save_for_backward(sig, rgb, zl, bgc)
         ctx.mark_non_differentiable(invdepth, zlog_s)
+        ctx.set_materialize_grads(False)
         return image, invdepth, weights, zlog_s
 
     @staticmethod
     def backward(ctx, dimage, _dinv, dweights, _dzs):
         sig, rgb, zl, bgc = ctx.saved_tensors
         N, S = sig.shape
+        if dimage is None and dweights is None:
+            return None, None, None, None, None, None, None
         if dimage is None:
             dimage = torch.zeros(N, 3, device=sig.device)
         dsig = torch.empty_like(sig)
