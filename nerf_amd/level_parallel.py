@@ -290,11 +290,17 @@ class LevelSharding(object):
         return a, b
 
     @torch.no_grad()
-    def sync_table(self, table):
-        """Broadcast every level from its owner so that all ranks hold the whole, current table."""
-        if self.world > 1 and self.dirty:
-            flat = table.view(-1)
+    def sync_levels(self, flat):
+        """Broadcast every level slice of a table-shaped tensor (the table, an Adam moment) from its owner."""
+        if self.world > 1:
+            flat = flat.view(-1)
             for l in range(self.cfg.n_levels):
                 a, b = self.level_slice(l)
                 parallel.broadcast_(flat[a:b], self.owner[l])
+
+    @torch.no_grad()
+    def sync_table(self, table):
+        """Broadcast every level from its owner so that all ranks hold the whole, current table."""
+        if self.dirty:
+            self.sync_levels(table)
         self.dirty = False

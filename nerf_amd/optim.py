@@ -151,6 +151,15 @@ class FusedAdam(torch.optim.Optimizer):
         check(lib().nerf_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), group['lr'], b1, b2, group['eps'],
                                    group['weight_decay'], step, self.grad_scale, 1, stream()), 'nerf_adam_step')
 
+    @torch.no_grad()
+    def sync_sharded_state(self):
+        """Level-sharded table: collect the Adam moments of every level from its owner (collective; needed before
+        the optimizer state is saved, so that a checkpoint can be resumed with any number of ranks)."""
+        if self._sharding is not None and self._table_param in self.state and self.state[self._table_param]:
+            st = self.state[self._table_param]
+            self._sharding.sync_levels(st['exp_avg'])
+            self._sharding.sync_levels(st['exp_avg_sq'])
+
     def table_reduced_by_pipeline(self):
         """True when the pending table gradient is being all-reduced level by level by the pipeline
         (the trainer must then leave the table out of its own gradient all-reduce)."""

@@ -85,6 +85,29 @@ class Trainer(object):
                         self.logger.log('Saving Model...')
                         self.logger.model(self.model, self.iter)
 
+    # ---- checkpoint / resume (the reference only saves model weights, logger.py:101-103) ----
+    def save_checkpoint(self, path):
+        """Model, optimizer moments, LR schedule and iteration count.  Collective under a level-sharded table
+        (every rank must call it); rank 0 writes the file."""
+        if hasattr(self.model, 'sync_table'):
+            self.model.sync_table()
+        if hasattr(self.optimizer, 'sync_sharded_state'):
+            self.optimizer.sync_sharded_state()
+        if parallel.rank() == 0:
+            torch.save({'iter': self.iter, 'model': self.model.state_dict(), 'optimizer': self.optimizer.state_dict(),
+                        'scheduler': self.scheduler.state_dict() if self.scheduler is not None else None}, path)
+
+    def load_checkpoint(self, path, map_location='cuda'):
+        ck = torch.load(path, map_location=map_location, weights_only=True)
+        self.model.load_state_dict(ck['model'])
+        self.optimizer.load_state_dict(ck['optimizer'])
+        if self.scheduler is not None and ck.get('scheduler') is not None:
+            self.scheduler.load_state_dict(ck['scheduler'])
+        self.iter = int(ck['iter'])
+        if getattr(self.model, 'direct_grads', False):     # load_state_dict keeps the tensors; make sure grads exist
+            self.model.enable_direct_grads(True)
+        return self
+
     def train_epoch(self, iters_per_epoch):
         for i in range(iters_per_epoch):
             self.optimizer.zero_grad()
