@@ -41,18 +41,14 @@ def sphere_cameras(n_img, seed=0, radius=4.0311 * 0.8, H=800, W=800, camera_angl
     return K, E
 
 
-class ProceduralSceneLoader(object):
-    def __init__(self, n_images=100, H=800, W=800, seed=0, device='cuda', images=None, batch_seed=0):
-        self.N, self.H, self.W = n_images, H, W
-        self.device = device
-        K, E = sphere_cameras(n_images, seed, H=H, W=W)
-        self.intrinsics = K.to(device)
-        self.extrinsics = E.to(device)
-        self.translation_center = torch.zeros(1, 3, device=device)   # the sphere is centred on the origin
-        self.depths_bool = False
-        # uint8 RGBA like the reference store (camera_geometry_loader.py:41); white opaque until rendered
-        self.images = images if images is not None else None
-        self.generator = torch.Generator(device=device).manual_seed(batch_seed)
+class DeviceBatchLoader(object):
+    """The batch interface of the reference's CameraGeometryLoader (camera_geometry_loader.py:68-152) over
+    device-resident stores: ``images`` uint8 [N,H,W,4], optional ``depths`` [N,H,W], ``intrinsics`` [N,3,3],
+    ``extrinsics`` [N,4,4], ``translation_center`` [1,3].  Subclasses fill the stores."""
+
+    images = None
+    depths = None
+    depths_bool = False
 
     def set_images(self, images_u8):
         assert images_u8.dtype == torch.uint8 and tuple(images_u8.shape) == (self.N, self.H, self.W, 4)
@@ -64,8 +60,11 @@ class ProceduralSceneLoader(object):
             color_bg = torch.rand(3, device=gt.device, generator=self.generator)
         else:
             color_bg = torch.tensor(background, dtype=torch.float32, device=gt.device)
-        rgba = gt.to(torch.float32) / 255
-        rgb_gt = rgba[..., :3] * rgba[..., 3:] + color_bg * (1 - rgba[..., 3:])
+        rgba = gt.to(torch.float32) / 255 if gt.dtype == torch.uint8 else gt
+        if rgba.shape[-1] == 4:
+            rgb_gt = rgba[..., :3] * rgba[..., 3:] + color_bg * (1 - rgba[..., 3:])
+        else:
+            rgb_gt = rgba
         return rgb_gt, color_bg
 
     def get_custom_batch(self, n, h, w, background=None, device='cuda'):
@@ -73,6 +72,7 @@ class ProceduralSceneLoader(object):
         n, h, w = n.to(self.device), h.to(self.device), w.to(self.device)
         K = self.intrinsics[n]
         E = self._centred_extrinsics()[n]
+        depth = self.depths[n, h, w] if (self.depths_bool and self.depths is not None) else None
         if self.images is not None:
             rgb_gt, color_bg = self.format_groundtruth(self.images[n, h, w, :], background)
         else:   # no rendered ground truth: deterministic pseudo-colours (throughput runs)
@@ -80,7 +80,7 @@ class ProceduralSceneLoader(object):
                         else torch.tensor(background, dtype=torch.float32, device=self.device))
             hw = torch.stack([h, w, h + w], -1)
             rgb_gt = (hw % 256).to(torch.float32) / 255
-        return n, h, w, K, E, rgb_gt, color_bg, None
+        return n, h, w, K, E, rgb_gt, color_bg, depth
 
     def _centred_extrinsics(self):
         """extrinsics with translation_center subtracted (camera_geometry_loader.py:95), cached per version of the
@@ -120,3 +120,18 @@ class ProceduralSceneLoader(object):
     def get_calibration(self, device='cuda'):
         """camera_geometry_loader.py:146-152."""
         return self.N, self.H, self.W, self.intrinsics, self._centred_extrinsics().clone()
+
+
+class ProceduralSceneLoader(DeviceBatchLoader):
+    def __init__(self, n_images=100, H=800, W=800, seed=0, device='cuda', images=None, batch_seed=0):
+        self.N, self.H, self.W = n_images, H, W
+        self.device = device
+        K, E = sphere_cameras(n_images, seed, H=H, W=W)
+        self.intrinsics = K.to(device)
+        self.extrinsics = E.to(device)
+        self.translation_center = torch.zeros(1, 3, device=device)   # the sphere is centred on the origin
+        self.depths_bool = False
+        # uint8 RGBA like the reference store (camera_geometry_loader.py:41); white opaque until rendered
+        self.images = images if images is not None else None
+        self.generator = torch.Generator(device=device).manual_seed(batch_seed)
+
