@@ -144,6 +144,8 @@ def main():
     ap.add_argument('--no-pipeline', action='store_true', help='dense table all-reduce + one Adam pass (no per-level pipeline)')
     ap.add_argument('--profile-steps', type=int, default=5)
     ap.add_argument('--table-log2', type=int, default=24, help='REHEARSAL ONLY: smaller hash table (the metric config is 24)')
+    ap.add_argument('--coarse', default='64', help="coarse sampling: '64' (metric config, z_bounds [1.6,4.8]) or "
+                    "'480' (config_base: steps [256,128,64,32], z_bounds [.1,1,10,100,1000]; SURVEY C1/C4 parity sizes)")
     ap.add_argument('--hang-trace', type=int, default=0, help='dump all Python stacks to stderr every N seconds')
     args = ap.parse_args()
     if args.hang_trace > 0:
@@ -159,6 +161,9 @@ def main():
     import torch.distributed as dist
 
     NET['encoding_log2_hashmap_size'] = args.table_log2
+    if args.coarse == '480':
+        STEPS[:] = [256, 128, 64, 32]
+        Z_BOUNDS[:] = [0.1, 1, 10, 100, 1000]
     model, renderer, loader, opt = build_gpu(device, rank, args.rays, pipeline=not args.no_pipeline)
     n_params = sum(p.numel() for g in opt.param_groups for p in g['params'])
     model_sharded = model.level_sharding
@@ -208,9 +213,9 @@ def main():
             per_level = n_pts_scatter * (2 * 8 * 2 * 4 + 2 * 4)     # RMW of 8 corners x F floats + F floats of dfeat
             bytes_step = per_level * lv * (launches / args.profile_steps)
         elif base == 'nerf_hashgrid_encode_levels':
-            bytes_step = algorithmic_bytes(base, args.rays, n_params)   # both launches of one step together
+            bytes_step = algorithmic_bytes(base, args.rays, n_params, Sc=sum(STEPS))   # both launches of one step together
         else:
-            b = algorithmic_bytes(base, args.rays, n_params)
+            b = algorithmic_bytes(base, args.rays, n_params, Sc=sum(STEPS))
             bytes_step = b * (launches / args.profile_steps) if b else None
         k = {'name': name, 'launches_per_step': launches / args.profile_steps, 'ms_per_step': round(per_step_ms, 4),
              'avg_launch_ms': round(total_ms / launches, 4)}
@@ -218,7 +223,7 @@ def main():
             k['algorithmic_bytes_per_launch'] = bytes_step / (launches / args.profile_steps)
             k['algorithmic_GBps'] = round(bytes_step / (per_step_ms * 1e-3) / 1e9, 1)
             k['hbm_frac'] = round(k['algorithmic_GBps'] / HBM_PEAK_GBS, 4)
-        fl = algorithmic_flops(base, args.rays)
+        fl = algorithmic_flops(base, args.rays, Sc=sum(STEPS))
         if fl:
             k['algorithmic_TFLOPs'] = round(fl / (per_step_ms * 1e-3) / 1e12, 2)
             k['mfma_f32_frac'] = round(k['algorithmic_TFLOPs'] / MFMA_F32_PEAK_TFLOPS, 4)
@@ -271,9 +276,10 @@ def main():
             'metric': 'rays/sec (train step + render) at 64+128 samples/ray', 'value': value, 'unit': 'rays/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'train step (render + backward + dense Adam), %d rays/GPU/step, 64 coarse + 128 fine '
-                                   'samples/ray, config_base network (L20 F2 T%d, SH4, latent 48, 64-wide MLPs), '
-                                   'procedural scene 100 poses 800x800' % (args.rays, args.table_log2),
+            'config': {'workload': ('train step (render + backward + dense Adam), %d rays/GPU/step, %d coarse + 128 fine '
+                                    'samples/ray, config_base network (L20 F2 T%d, SH4, latent 48, 64-wide MLPs), '
+                                    'procedural scene 100 poses 800x800' % (args.rays, sum(STEPS), args.table_log2))
+                                   + ('' if args.coarse == '64' else ' [NOT the metric config: %s coarse samples]' % args.coarse),
                        'rays_per_gpu': args.rays, 'global_rays': args.rays * world, 'parallelism': ('dp%d over rays' % world) + (', hash table sharded by level (feature all-to-all)'
                                                                     if getattr(model_sharded, 'world', 1) > 1 else '')},
             'roofline': roofline, 'roofline_second': roofline_2, 'cpu_baseline': cpu, 'render': render, 'kernels': kernels,
