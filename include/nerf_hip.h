@@ -142,6 +142,12 @@ int nerf_field_bwd(const NerfGridCfg* grid, const NerfNetCfg* net, const float* 
 int nerf_hashgrid_scatter(const NerfGridCfg* grid, const NerfPointSrc* src, const float* dfeat /*[M,L*F]*/,
                           float* dtable, int level_begin, int level_count, void* stream);
 
+/* d(loss)/d(x) of NeRFNetwork.density (nets.py:148-164) for dL/dsigma = dsigma: the input gradient autograd + tcnn
+ * deliver when the pose alignment differentiates model.density through the sample points
+ * (allign/trainer.py:174-208).  Points mode only; dx [M,3] is w.r.t. the positions in src->x. */
+int nerf_density_bwd_input(const NerfGridCfg* grid, const NerfNetCfg* net, const float* table, const float* sigma_params,
+                           const NerfPointSrc* src, const float* dsigma /*[M]*/, float* dx /*[M,3]*/, void* stream);
+
 /* ---- level-sharded hash table (no counterpart in the single-GPU reference) ----
  * Under multi-GPU training every rank owns a subset of the hash-grid levels.  The owner evaluates
  * tcnn.Encoding (nets.py:118,154) for ITS levels on the sample points of all ranks, the per-point feature

@@ -63,6 +63,7 @@ SIGNATURES = {
     'nerf_density_fwd': (_I, [_G, _N, _P, _P, _S, _P, _P, _P]),
     'nerf_field_fwd': (_I, [_G, _N, _P, _P, _P, _P, _I64, _S, _P, _P, _P, _P, _P]),
     'nerf_field_bwd': (_I, [_G, _N, _P, _P, _P, _P, _I64, _S, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'nerf_density_bwd_input': (_I, [_G, _N, _P, _P, _S, _P, _P, _P]),
     'nerf_hashgrid_scatter': (_I, [_G, _S, _P, _P, _I, _I, _P]),
     'nerf_hashgrid_encode_levels': (_I, [_G, _P, _S, _LS, _P, _I64, _P]),
     'nerf_hashgrid_scatter_levels': (_I, [_G, _S, _LS, _P, _I64, _P, _P]),

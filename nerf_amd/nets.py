@@ -219,6 +219,35 @@ class _FieldFn(torch.autograd.Function):
         return dtable, dsw, dcw, dlat, None, None, None
 
 
+class _DensityInputGradFn(torch.autograd.Function):
+    """sigma = density(x) with the gradient w.r.t. the positions only (nerf_density_bwd_input): what the pose
+    alignment needs (allign/trainer.py:174-208: two frozen fields, the rigid transform is optimised).  Parameter
+    gradients flow through forward(), not through density()."""
+
+    @staticmethod
+    def forward(ctx, x, net, outer_bound):
+        xx = f32(x).reshape(-1, 3)
+        sigma, xh = net.density_src(make_point_src(outer_bound, x=xx, n_points=xx.shape[0]), want_features=True)
+        ctx.save_for_backward(xx)
+        ctx.net, ctx.outer_bound, ctx.shape = net, outer_bound, x.shape
+        ctx.mark_non_differentiable(xh)
+        ctx.set_materialize_grads(False)
+        return sigma, xh
+
+    @staticmethod
+    def backward(ctx, dsigma, _dxh):
+        if dsigma is None:
+            return None, None, None
+        (xx,) = ctx.saved_tensors
+        net = ctx.net
+        src = make_point_src(ctx.outer_bound, x=xx, n_points=xx.shape[0])
+        dx = torch.empty_like(xx)
+        check(lib().nerf_density_bwd_input(C.byref(net.encoder.cfg), C.byref(net.net_cfg), ptr(net.encoder.params),
+                                           ptr(net.sigma_net.params), C.byref(src), ptr(f32(dsigma).reshape(-1)), ptr(dx),
+                                           stream()), 'nerf_density_bwd_input')
+        return dx.reshape(ctx.shape), None, None
+
+
 class _ShardedFieldFn(torch.autograd.Function):
     """_FieldFn under a level-sharded table (level_parallel.py): features arrive by all-to-all from the level
     owners, d(features) returns the same way; only this rank's levels receive table gradient."""
@@ -396,9 +425,19 @@ class NeRFNetwork(nn.Module):
         sigma, rgb, xh, _ = self._field(dict(outer_bound=outer_bound, x=xx, d=dd, n=nn_, n_points=xx.shape[0]))
         return sigma.reshape(*prefix), rgb.reshape(*prefix, 3), {'x_hashtable': xh.reshape(*prefix, -1).detach()}
 
-    @torch.no_grad()
     def density(self, x, outer_bound):
-        """nets.py:148-164 (only ever called without grad: renderer.py:145,152)."""
+        """nets.py:148-164.  The renderer calls it without grad (renderer.py:145,152); when x requires grad (pose
+        alignment, allign/trainer.py:188) sigma carries the gradient w.r.t. x (not w.r.t. the parameters)."""
+        prefix = x.shape[:-1]
+        if torch.is_grad_enabled() and x.requires_grad:
+            with self.local_table():
+                sigma, xh = _DensityInputGradFn.apply(x, self, outer_bound)
+            return sigma.reshape(*prefix), {'x_hashtable': xh.reshape(*prefix, -1)}
+        with torch.no_grad():
+            return self._density_nograd(x, outer_bound)
+
+    @torch.no_grad()
+    def _density_nograd(self, x, outer_bound):
         prefix = x.shape[:-1]
         xx = f32(x).reshape(-1, 3)
         sigma, xh = self.density_kw(dict(outer_bound=outer_bound, x=xx, n_points=xx.shape[0]), want_features=True)

@@ -524,3 +524,53 @@ def extract_dense_geometry(model, mask, voxel_res, batch_size, thresh, outer_bou
     if not points:
         return torch.zeros(0, 3), torch.zeros(0, 3)
     return torch.cat(points), torch.cat(colors)
+
+
+# --------------------------------------------------------------------------------------
+# Pose-alignment consistency step (allign/trainer.py:174-208, allign/allign2.py:35-56, allign/rotation.py:8-27)
+# --------------------------------------------------------------------------------------
+
+def so3_exp(r):
+    """allign/rotation.py:18-27 with vec2skew of :8-15."""
+    z = torch.zeros(1)
+    skew = torch.stack([torch.cat([z, -r[2:3], r[1:2]]), torch.cat([r[2:3], z, -r[0:1]]), torch.cat([-r[1:2], r[0:1], z])])
+    n = r.norm() + 1e-15
+    return torch.eye(3) + (torch.sin(n) / n) * skew + ((1 - torch.cos(n)) / n ** 2) * (skew @ skew)
+
+
+def rigid_transform(xyzs_a, init_transform, R, T):
+    """allign/allign2.py:44-56 (homogeneous products written out)."""
+    tr = torch.eye(4)
+    tr[:3, :3] = so3_exp(R)
+    tr[:3, 3] = T
+    b = xyzs_a.reshape(-1, 3)
+    b1 = torch.cat([b, b.new_ones((b.shape[0], 1))], dim=1)
+    b3 = (tr @ (init_transform @ b1.T)).T
+    return b3[:, :3].reshape(*xyzs_a.shape)
+
+
+def scene_consistency(renderer_a, model_a, model_b, init_transform, R, T, h, w, K, E, noise=None):
+    """allign/trainer.py:174-208, line by line (the [N,S,S] outer product included)."""
+    rays_o, rays_d = renderer_a.get_rays(h, w, K, E)
+    z_vals_log, z_vals = renderer_a.efficient_sampling(rays_o, rays_d, renderer_a.steps_importance,
+                                                       renderer_a.alpha_importance, noise=noise)
+    xyzs_a, _ = renderer_a.get_sample_points(rays_o, rays_d, z_vals)
+    s_xyzs_a = renderer_a.mipnerf360_scale(xyzs_a, renderer_a.inner_bound, renderer_a.outer_bound)
+    sigmas_a, _ = model_a.density(s_xyzs_a, renderer_a.outer_bound)
+    delta = z_vals_log.new_zeros(z_vals_log.shape)
+    delta[:, :-1] = (z_vals_log[:, 1:] - z_vals_log[:, :-1])
+    alpha_a = 1 - torch.exp(-sigmas_a * delta)
+    alpha_a_shift = torch.cat([alpha_a.new_zeros((alpha_a.shape[0], 1)), alpha_a], dim=-1)[:, :-1]
+    weights_a = alpha_a * torch.cumprod(1 - alpha_a_shift, dim=-1)
+    xyzs_b = rigid_transform(xyzs_a, init_transform, R, T)
+    s_xyzs_b = renderer_a.mipnerf360_scale(xyzs_b, renderer_a.inner_bound, renderer_a.outer_bound)
+    sigmas_b, _ = model_b.density(s_xyzs_b, renderer_a.outer_bound)
+    sigmas_ab = sigmas_a + sigmas_b
+    alpha_ab = 1 - torch.exp(-sigmas_ab * delta)
+    alpha_ab_shift = torch.cat([alpha_ab.new_zeros((alpha_ab.shape[0], 1)), alpha_ab], dim=-1)[:, :-1]
+    weights_ab = alpha_ab * torch.cumprod(1 - alpha_ab_shift, dim=-1)
+    weights_a = torch.cat([weights_a[:, :-1], (1 - torch.sum(weights_a[:, :-1], dim=-1))[:, None]], -1)
+    weights_ab = torch.cat([weights_ab[:, :-1], (1 - torch.sum(weights_ab[:, :-1], dim=-1))[:, None]], -1)
+    wgt = torch.bmm(weights_a[:, :, None], weights_ab[:, None, :])
+    s = torch.abs(z_vals_log[:, :, None] - z_vals_log[:, None, :])
+    return torch.mean(torch.sum(wgt * s, dim=[1, 2]))
