@@ -72,7 +72,7 @@ def algorithmic_flops(name, n_rays, Sc=64, Sf=SF):
             'nerf_density_from_features': n_rays * Sc * 7168}.get(name)
 
 
-def build_gpu(device, rank, n_rays, pipeline=True):
+def build_gpu(device, rank, n_rays, pipeline=True, shard_levels=None):
     from nerf_amd.loaders.procedural import ProceduralSceneLoader
     from nerf_amd.nets import NeRFNetwork
     from nerf_amd.optim import FusedAdam
@@ -84,7 +84,7 @@ def build_gpu(device, rank, n_rays, pipeline=True):
         {'name': 'encoding', 'params': list(model.encoder.parameters()), 'lr': 2e-2},
         {'name': 'latent_emb', 'params': [model.latent_emb], 'lr': 2e-2},
         {'name': 'net', 'params': list(model.sigma_net.parameters()) + list(model.color_net.parameters()),
-         'weight_decay': 1e-6, 'lr': 1e-3}], betas=(0.9, 0.99), eps=1e-15).attach(model, pipeline=pipeline)
+         'weight_decay': 1e-6, 'lr': 1e-3}], betas=(0.9, 0.99), eps=1e-15).attach(model, pipeline=pipeline, shard_levels=shard_levels)
     return model, renderer, loader, opt
 
 
@@ -165,6 +165,20 @@ def main():
         STEPS[:] = [256, 128, 64, 32]
         Z_BOUNDS[:] = [0.1, 1, 10, 100, 1000]
     model, renderer, loader, opt = build_gpu(device, rank, args.rays, pipeline=not args.no_pipeline)
+    fallback_note = ''
+    if world > 1 and model.level_sharding is not None:
+        # The level-sharded exchange has only ever run over gloo (one-GPU box); if its first step raises over RCCL --
+        # an API-level error is raised on every rank alike -- fall back to the replicated table, and say so.
+        try:
+            train_step(model, renderer, loader, opt, args.rays, 0, world)
+            torch.cuda.synchronize()
+        except Exception as e:      # noqa: BLE001
+            fallback_note = ' [level-sharded path failed (%s: %s); replicated table]' % (type(e).__name__, str(e)[:200])
+            sys.stderr.write('rank %d:%s\n' % (rank, fallback_note))
+            del model, renderer, loader, opt
+            torch.cuda.empty_cache()
+            model, renderer, loader, opt = build_gpu(device, rank, args.rays, pipeline=not args.no_pipeline,
+                                                     shard_levels=False)
     n_params = sum(p.numel() for g in opt.param_groups for p in g['params'])
     model_sharded = model.level_sharding
     if model_sharded is not None:      # this rank's Adam pass only covers the levels it owns
@@ -281,7 +295,7 @@ def main():
                                     'procedural scene 100 poses 800x800' % (args.rays, sum(STEPS), args.table_log2))
                                    + ('' if args.coarse == '64' else ' [NOT the metric config: %s coarse samples]' % args.coarse),
                        'rays_per_gpu': args.rays, 'global_rays': args.rays * world, 'parallelism': ('dp%d over rays' % world) + (', hash table sharded by level (feature all-to-all)'
-                                                                    if getattr(model_sharded, 'world', 1) > 1 else '')},
+                                                                    if getattr(model_sharded, 'world', 1) > 1 else '') + fallback_note},
             'roofline': roofline, 'roofline_second': roofline_2, 'cpu_baseline': cpu, 'render': render, 'kernels': kernels,
         }
         print(json.dumps(out), flush=True)

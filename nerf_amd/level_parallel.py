@@ -21,6 +21,7 @@ Between optimizer steps a rank's copy of the levels it does NOT own is stale; `s
 level from its owner (needed before inference, extraction or a checkpoint).
 """
 import ctypes as C
+import os
 
 import torch
 import torch.distributed as dist
@@ -186,6 +187,8 @@ class LevelSharding(object):
         buffer) while the exchange is in flight, wait, one shuffle pass into level-major rows."""
         W, r, wm = self.world, self.rank, self.width[self.rank]
         dev = table.device
+        if os.environ.get('NERF_TEST_SHARD_FAIL'):      # rehearsal hook for bench.py's replicated-table fallback
+            raise RuntimeError('injected failure (NERF_TEST_SHARD_FAIL)')
         send = torch.empty(W * m_local * wm, device=dev, dtype=torch.float32)
         recv = torch.empty(m_local * sum(self.width), device=dev, dtype=torch.float32)
         send_blocks = self._blocks(send, m_local, [wm] * W)
