@@ -63,7 +63,7 @@ class Inferencer(object):
         for a, b in self._chunks(total):
             nz = None if noise is None else noise[a:b]
             image_fb, _, _, aux = self.renderer.render(n_f[a:b], h_f[a:b], w_f[a:b], K_f[a:b], E_f[a:b],
-                                                       bg_color=self._white(dev), noise=nz)
+                                                       bg_color=self._white(dev), noise=nz, aux=False)
             image_l[a - a0:b - a0] = image_fb
             invdepth_l[a - a0:b - a0] = aux['invdepth']
         image_f = parallel.gather_slices(image_l, total)

@@ -418,6 +418,19 @@ class NeRFNetwork(nn.Module):
         return _FieldFn.apply(self.encoder.params, self.sigma_net.params, self.color_net.params, self.latent_emb, self,
                               src_kwargs, want_xyz)
 
+    @torch.no_grad()
+    def field_nograd(self, src_kwargs):
+        """sigma, rgb for inference: no autograd node, and neither x_hashtable (160 B/point) nor xyz is written."""
+        with self.local_table():
+            src = make_point_src(**src_kwargs)
+            dev = self.encoder.params.device
+            sigma = torch.empty(src.n_points, device=dev, dtype=torch.float32)
+            rgb = torch.empty(src.n_points, 3, device=dev, dtype=torch.float32)
+            check(lib().nerf_field_fwd(C.byref(self.encoder.cfg), C.byref(self.net_cfg), ptr(self.encoder.params),
+                                       ptr(self.sigma_net.params), ptr(self.color_net.params), ptr(self.latent_emb), self.N,
+                                       C.byref(src), ptr(sigma), ptr(rgb), None, None, stream()), 'nerf_field_fwd')
+        return sigma, rgb
+
     def forward(self, x, d, n, outer_bound):
         """nets.py:109-146.  x: contracted points [...,3], d: unit dirs [...,3], n: image index [...]."""
         prefix = x.shape[:-1]

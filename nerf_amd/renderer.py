@@ -207,13 +207,20 @@ class NerfRenderer(nn.Module):
                                         len(self.steps_firstpass), ptr(zlog_f), ptr(z_f), stream()), 'nerf_coarse_to_fine')
         return zlog_f, z_f
 
-    def render(self, n, h, w, K, E, bg_color, noise=None, generator=None):
-        """renderer.py:170-194."""
+    def render(self, n, h, w, K, E, bg_color, noise=None, generator=None, aux=True):
+        """renderer.py:170-194.  ``aux=False`` (inference only, no grad): the per-sample aux outputs ``xyzs`` and
+        ``x_hashtable`` are not produced (172 B per sample that render_image never reads)."""
         rays_o, rays_d = self.get_rays(h, w, K, E)
         z_vals_log, z_vals = self.efficient_sampling(rays_o, rays_d, self.steps_importance, self.alpha_importance,
                                                      noise=noise, generator=generator)
         N, Sf = z_vals.shape
-        if isinstance(self.model, NeRFNetwork):
+        lean = (not aux) and (not torch.is_grad_enabled()) and isinstance(self.model, NeRFNetwork)
+        if lean:
+            sigmas, rgbs = self.model.field_nograd(
+                dict(outer_bound=self.outer_bound, rays_o=rays_o, rays_d=rays_d, z=z_vals, z_stride=Sf, n_samples=Sf,
+                     n_points=N * Sf, n=i64(n).reshape(-1), inner_bound=self.inner_bound))
+            sigmas, rgbs, xyzs, x_hashtable = sigmas.view(N, Sf), rgbs.view(N, Sf, 3), None, None
+        elif isinstance(self.model, NeRFNetwork):
             nn_ = i64(n).reshape(-1)
             sigmas, rgbs, xh, xyzs = self.model._field(
                 dict(outer_bound=self.outer_bound, rays_o=rays_o, rays_d=rays_d, z=z_vals, z_stride=Sf, n_samples=Sf,
@@ -237,6 +244,6 @@ class NerfRenderer(nn.Module):
         aux_outputs['z_vals_log'] = z_vals_log.detach()
         aux_outputs['sigmas'] = sigmas.detach()
         aux_outputs['rgbs'] = rgbs.detach()
-        aux_outputs['xyzs'] = xyzs.detach()
+        aux_outputs['xyzs'] = xyzs.detach() if xyzs is not None else None
         aux_outputs['x_hashtable'] = x_hashtable
         return image, weights, z_vals_log_s, aux_outputs
