@@ -128,7 +128,11 @@ def cpu_baseline(n_rays=1024, steps=2, threads=16):
         opt.step()
         times.append(time.perf_counter() - t0)
     t = sorted(times[1:])[len(times[1:]) // 2]
-    return {'value': n_rays / t, 'unit': 'rays/s', 'cores': threads, 'kind': 'port',
+    with torch.no_grad():           # forward-only render of the same rays (the inference half of the metric)
+        t0 = time.perf_counter()
+        R.render(n, h, w, K_all[n], E_all[n], bg)
+        t_render = time.perf_counter() - t0
+    return {'value': n_rays / t, 'unit': 'rays/s', 'cores': threads, 'kind': 'port', 'render_rays_per_s': n_rays / t_render,
             'sample': '%d train steps of %d rays (1 warm-up), oracle/ref_cpu.py fp32 torch CPU, same network/renderer config'
                       % (steps, n_rays), 'seconds_per_step': t}
 
