@@ -217,6 +217,9 @@ def main():
     prof = _lib.kernel_timing(False) if args.profile_steps > 0 else {}
     kernels = []
     n_pts_scatter = args.rays * SF * (world if model_sharded is not None else 1)
+    pipe = model.table_pipeline
+    # the backward may run as two ray chunks (nets._FieldFn.backward): every level is then scattered by two launches
+    n_chunks = 2 if (pipe is not None and model_sharded is None and pipe.early_events) else 1
     for name, (launches, total_ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
         per_step_ms = total_ms / args.profile_steps
         base = name.split('[')[0]
@@ -229,7 +232,7 @@ def main():
         elif base in ('nerf_hashgrid_scatter', 'nerf_hashgrid_scatter_levels'):
             lv = int(cls[1:].split(' ')[0])             # levels per launch
             per_level = n_pts_scatter * (2 * 8 * 2 * 4 + 2 * 4)     # RMW of 8 corners x F floats + F floats of dfeat
-            bytes_step = per_level * lv * (launches / args.profile_steps)
+            bytes_step = per_level * lv * (launches / args.profile_steps) / n_chunks
         elif base == 'nerf_hashgrid_encode_levels':
             bytes_step = algorithmic_bytes(base, args.rays, n_params, Sc=sum(STEPS))   # both launches of one step together
         else:

@@ -40,7 +40,8 @@ def main():
     ap.add_argument('--steps', type=int, required=True, help='training steps executed by the profiled command')
     ap.add_argument('--out', default=None)
     ap.add_argument('--adam-grid', type=int, default=4194304, help='Grid_Size of the Adam launch on one hashed level')
-    ap.add_argument('--scatter-points', type=int, default=4096 * 128, help='sample points per scatter launch')
+    ap.add_argument('--levels-per-chunk', type=int, default=15, help='single-level scatter_kernel launches per backward chunk')
+    ap.add_argument('--hashed-per-chunk', type=int, default=11, help='of which hashed levels (issued first)')
     ap.add_argument('dirs', nargs='+')
     a = ap.parse_args()
     tot = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -58,14 +59,19 @@ def main():
                         break
     # per-launch figures for the launch classes bench.py times separately (same names as nerf_amd._lib._launch_class)
     per_launch = collections.defaultdict(lambda: collections.defaultdict(list))
+    seq = collections.defaultdict(int)
     for d in a.dirs:
         for f in glob.glob(d + '/**/*_counter_collection.csv', recursive=True):
             for row in csv.DictReader(open(f)):
                 kn, grid = row['Kernel_Name'], int(row['Grid_Size'])
                 cls = None
                 if re.search(r'scatter_kernel<', kn):
-                    cls = ('nerf_hashgrid_scatter[1 hashed level]' if grid == a.scatter_points * 16
-                           else 'nerf_hashgrid_scatter[%d dense levels]' % (grid // (a.scatter_points * 16)))
+                    # host issue order per backward chunk: the hashed levels one by one, then the big dense levels one
+                    # by one (nerf_amd/optim.py TablePipeline order 'A'); the small dense levels use scatter_small_kernel
+                    key = (f, row['Counter_Name'])
+                    pos = seq[key] % a.levels_per_chunk
+                    seq[key] += 1
+                    cls = 'nerf_hashgrid_scatter[1 hashed level]' if pos < a.hashed_per_chunk else 'nerf_hashgrid_scatter[1 dense level]'
                 elif re.search(r'adam_kernel', kn) and grid == a.adam_grid:
                     cls = 'adam_table_slice'
                 if cls:
