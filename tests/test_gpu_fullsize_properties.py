@@ -1,0 +1,153 @@
+"""Full-size checks (the metric configuration: config_base network with the 2^24 table, 4096 rays, 64 + 128
+samples) through size-independent properties -- the oracle cannot run these sizes in test time:
+adjointness of gather and scatter, sortedness of the resampled depths, compositing identities, independence of
+the batch split, determinism, additivity of gradients over the batch, closed-form Adam steps on the whole table."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+NET = dict(encoding_precision='float32', encoding_n_levels=20, encoding_n_features_per_level=2,
+           encoding_log2_hashmap_size=24, geo_feat_dim=15, sigma_hidden_dim=64, sigma_num_layers=2,
+           encoding_dir_precision='float32', encoding_dir_encoding='SphericalHarmonics', encoding_dir_degree=4,
+           latent_embedding_dim=48, color_hidden_dim=64, color_num_layers=3)
+N_RAYS, SF = 4096, 128
+
+
+@pytest.fixture(scope='module')
+def scene():
+    from nerf_amd.loaders.procedural import ProceduralSceneLoader
+    from nerf_amd.nets import NeRFNetwork
+    from nerf_amd.renderer import NerfRenderer
+    net = NeRFNetwork(100, seed=0, **NET)
+    with torch.no_grad():
+        net.encoder.params.mul_(3e3)                        # features of order 0.3: densities that matter
+        net.latent_emb.normal_(0, 0.3, generator=torch.Generator(device='cuda').manual_seed(1))
+    R = NerfRenderer(net, 2, 2.5, [1.6, 4.8], [64], SF, 0.2)
+    loader = ProceduralSceneLoader(100, 800, 800, seed=0, batch_seed=7)
+    n, h, w, K, E, gt, bg, _ = loader.get_random_batch(N_RAYS)
+    noise = torch.rand(N_RAYS, SF, device='cuda', generator=torch.Generator(device='cuda').manual_seed(2))
+    yield net, R, (n, h, w, K, E, gt, bg, noise)
+    del net, R
+    torch.cuda.empty_cache()
+
+
+def test_gather_and_scatter_are_adjoint_at_full_size(scene):
+    """<gather(T; x), D> == <T, scatter(D; x)> for the 200 M-entry table and 524 288 sample points."""
+    from nerf_amd._lib import check, lib, ptr, stream
+    from nerf_amd.nets import make_point_src
+    net, R, (n, h, w, K, E, gt, bg, noise) = scene
+    cfg = net.encoder.cfg
+    rays_o, rays_d = R.get_rays(h, w, K, E)
+    _, z = R.efficient_sampling(rays_o, rays_d, SF, 0.2, noise=noise)
+    M = N_RAYS * SF
+    src = make_point_src(2.5, rays_o=rays_o, rays_d=rays_d, z=z, z_stride=SF, n_samples=SF, n_points=M, inner_bound=2.0)
+    g = torch.Generator(device='cuda').manual_seed(5)
+    T = torch.randn(net.encoder.params.numel(), device='cuda', generator=g)
+    D = torch.randn(M, cfg.n_levels * cfg.n_features, device='cuda', generator=g)
+    from nerf_amd._lib import NerfLevelSet
+    every = NerfLevelSet()
+    every.count = cfg.n_levels
+    for l in range(cfg.n_levels):
+        every.level[l] = l
+    feats = torch.empty_like(D)
+    check(lib().nerf_hashgrid_encode_levels(C.byref(cfg), ptr(T), C.byref(src), C.byref(every), ptr(feats), D.shape[1],
+                                            stream()), 'encode')
+    S = torch.zeros_like(T)
+    check(lib().nerf_hashgrid_scatter(C.byref(cfg), C.byref(src), ptr(D), ptr(S), 0, cfg.n_levels, stream()), 'scatter')
+    lhs = float((feats.double() * D.double()).sum())
+    rhs = float((T.double() * S.double()).sum())
+    scale = float((feats.double() * D.double()).abs().sum())
+    assert abs(lhs - rhs) <= 2e-6 * scale, (lhs, rhs, scale)
+    # level by level too (catches a level written into another level's slice)
+    for l in (0, 4, 8, 9, 19):
+        a = int(cfg.offset[l]) * 2
+        b = (int(cfg.offset[l + 1]) if l + 1 < cfg.n_levels else int(cfg.total_entries)) * 2
+        lhs_l = float((feats[:, 2 * l:2 * l + 2].double() * D[:, 2 * l:2 * l + 2].double()).sum())
+        rhs_l = float((T[a:b].double() * S[a:b].double()).sum())
+        sc = float((feats[:, 2 * l:2 * l + 2].double() * D[:, 2 * l:2 * l + 2].double()).abs().sum())
+        assert abs(lhs_l - rhs_l) <= 5e-6 * sc, (l, lhs_l, rhs_l)
+
+
+def test_render_identities_at_full_size(scene):
+    net, R, (n, h, w, K, E, gt, bg, noise) = scene
+    with torch.no_grad():
+        img, wts, zs, aux = R.render(n, h, w, K, E, bg, noise=noise)
+        # resampled depths: sorted, inside the coarse range
+        zl = aux['z_vals_log']
+        assert bool((zl[:, 1:] >= zl[:, :-1]).all())
+        import math
+        assert float(zl.min()) >= math.log10(1.6) - 1e-6 and float(zl.max()) <= math.log10(4.8) + 1e-6
+        assert bool((zs >= -1e-6).all()) and bool((zs <= 1 + 1e-6).all())
+        # weights: a sub-probability distribution per ray
+        assert bool((wts >= 0).all()) and float(wts.sum(-1).max()) <= 1 + 1e-5
+        acc = wts.sum(-1, keepdim=True)
+        # image = sum w c + (1 - sum w) bg : exact affine dependence on the background
+        bg2 = torch.tensor([0.9, 0.1, 0.4], device='cuda')
+        img2, wts2, _, aux2 = R.render(n, h, w, K, E, bg2, noise=noise)
+        assert torch.equal(wts, wts2) and torch.equal(aux['rgbs'], aux2['rgbs'])
+        torch.testing.assert_close(img2 - img, (1 - acc) * (bg2 - bg), rtol=0, atol=2e-6)
+        torch.testing.assert_close(img, (wts[..., None] * aux['rgbs']).sum(1) + (1 - acc) * bg, rtol=0, atol=1e-5)
+        torch.testing.assert_close(aux['invdepth'], (wts / aux['z_vals']).sum(-1), rtol=1e-5, atol=1e-6)
+        # determinism and independence of how the batch is split (per-ray / per-point kernels)
+        img3, wts3, _, _ = R.render(n, h, w, K, E, bg, noise=noise)
+        assert torch.equal(img, img3) and torch.equal(wts, wts3)
+        cut = 1337
+        a = R.render(n[:cut], h[:cut], w[:cut], K[:cut], E[:cut], bg, noise=noise[:cut])
+        b = R.render(n[cut:], h[cut:], w[cut:], K[cut:], E[cut:], bg, noise=noise[cut:])
+        assert torch.equal(torch.cat([a[0], b[0]]), img) and torch.equal(torch.cat([a[1], b[1]]), wts)
+        # the lean inference path computes the same image
+        img4, _, _, aux4 = R.render(n, h, w, K, E, bg, noise=noise, aux=False)
+        assert torch.equal(img4, img) and aux4['x_hashtable'] is None
+
+
+def test_gradients_add_up_over_the_batch(scene):
+    """d(sum-loss)/d(params) of the whole batch == sum over two sub-batches (gradient accumulation is linear)."""
+    from nerf_amd import helpers
+    net, R, (n, h, w, K, E, gt, bg, noise) = scene
+    params = [net.sigma_net.params, net.color_net.params, net.latent_emb, net.encoder.params]
+
+    def grads(sl, scale):
+        for p in params:
+            p.grad = None
+        img, wts, zs, _ = R.render(n[sl], h[sl], w[sl], K[sl], E[sl], bg, noise=noise[sl])
+        loss, _ = helpers.fused_train_loss(img, gt[sl], wts, zs, 1e-3, 1e-1)
+        (loss * scale).backward()
+        torch.cuda.synchronize()
+        return [p.grad.detach().clone() for p in params]
+    cut = 1500
+    whole = grads(slice(None), 1.0)
+    ga = grads(slice(0, cut), cut / N_RAYS)                 # the losses are means over rays
+    gb = grads(slice(cut, None), (N_RAYS - cut) / N_RAYS)
+    for p in params:
+        p.grad = None
+    for gw, a, b, name in zip(whole, ga, gb, ('sigma_net', 'color_net', 'latent', 'table')):
+        s = float(gw.abs().max())
+        assert s > 0, name
+        torch.testing.assert_close(a + b, gw, rtol=1e-3, atol=2e-5 * s, msg=lambda m, nm=name: nm + ': ' + m)
+
+
+def test_adam_closed_form_on_the_whole_table(scene):
+    from nerf_amd._lib import check, lib, ptr, stream
+    net, _, _ = scene
+    n = net.encoder.params.numel()
+    p = torch.randn(n, device='cuda', generator=torch.Generator(device='cuda').manual_seed(9))
+    p0 = p.clone()
+    g = torch.zeros(n, device='cuda')
+    m, v = torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
+    # (1) untouched entries (g = m = v = 0) do not move: 0 / (0 + eps) = 0
+    check(lib().nerf_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), n, 2e-2, 0.9, 0.99, 1e-15, 0.0, 1, 1.0, 1, stream()), 'adam')
+    assert torch.equal(p, p0) and float(m.abs().max()) == 0 and float(v.abs().max()) == 0
+    # (2) first step with a gradient: m_hat / sqrt(v_hat) = sign(g), so every touched entry moves by exactly lr
+    idx = torch.randint(0, n, (1 << 22,), device='cuda', generator=torch.Generator(device='cuda').manual_seed(10))
+    g[idx] = torch.randn(idx.numel(), device='cuda', generator=torch.Generator(device='cuda').manual_seed(11)) + 3.0
+    gref = g.clone()
+    check(lib().nerf_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), n, 2e-2, 0.9, 0.99, 1e-15, 0.0, 1, 1.0, 1, stream()), 'adam')
+    moved = gref != 0
+    torch.testing.assert_close((p0 - p)[moved], 2e-2 * torch.sign(gref[moved]), rtol=2e-5, atol=1e-7)
+    assert torch.equal(p[~moved], p0[~moved])
+    assert float(g.abs().max()) == 0                                        # cleared in the same pass
+    torch.testing.assert_close(m[moved], 0.1 * gref[moved], rtol=1e-5, atol=0)
+    torch.testing.assert_close(v[moved], 0.01 * gref[moved] ** 2, rtol=1e-5, atol=0)
