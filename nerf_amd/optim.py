@@ -31,9 +31,9 @@ class TablePipeline(object):
             big = [(l, 1) for l in reversed(dense) if l not in small]
             small = [(small[0], len(small))] if small and small == list(range(small[0], small[0] + len(small))) else \
                     [(l, 1) for l in small]
-            order = os.environ.get('NERF_PIPE_ORDER', 'A')
-            groups = {'A': hashed + big + small, 'B': small + big + hashed, 'C': small + hashed + big,
-                      'D': big + hashed + small}[order]
+            # hashed levels first (most Adam work released per scatter), small levels last: measured best of the
+            # four obvious orders
+            groups = hashed + big + small
         else:       # owned levels are not contiguous: one group each, big hashed levels first
             groups = [(l, 1) for l in sorted(levels, key=lambda l: (-int(grid_cfg.entries[l]), l))]
         self.groups = groups

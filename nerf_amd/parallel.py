@@ -156,20 +156,6 @@ def all_gather_rows(local):
     return out
 
 
-def all_to_all_flat(send, send_splits, recv_splits):
-    """Flat all-to-all: chunk r of `send` (send_splits[r] elements) goes to rank r; returns the concatenation
-    of the chunks received (recv_splits[r] elements from rank r)."""
-    send = send.contiguous().view(-1)
-    if _stage_cpu(send):
-        s = send.cpu()
-        out = torch.empty(sum(recv_splits), dtype=s.dtype)
-        dist.all_to_all_single(out, s, list(recv_splits), list(send_splits))
-        return out.to(send.device)
-    out = send.new_empty(sum(recv_splits))
-    dist.all_to_all_single(out, send, list(recv_splits), list(send_splits))
-    return out
-
-
 def all_to_all_blocks(recv_blocks, send_blocks, async_op=False):
     """send_blocks[r] -> rank r, recv_blocks[r] <- rank r (flat, contiguous views; sizes must match pairwise).
     The caller's OWN block is not transferred -- callers fill / consume it locally while the exchange is in flight.
