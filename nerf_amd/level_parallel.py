@@ -113,6 +113,7 @@ class LevelSharding(object):
             inv[c] = i
         self.inv = torch.tensor(inv, device=device, dtype=torch.int64)
         self._colmaps = {}
+        self.force = False      # run the exchange code even in a world of one rank (exercises the RCCL calls on one GPU)
         self.dirty = False      # True once an optimizer step made the non-owned levels of the local table stale
 
     # ---- point sources of all ranks -------------------------------------------------------
@@ -295,7 +296,7 @@ class LevelSharding(object):
     @torch.no_grad()
     def sync_levels(self, flat):
         """Broadcast every level slice of a table-shaped tensor (the table, an Adam moment) from its owner."""
-        if self.world > 1:
+        if dist.is_initialized():
             flat = flat.view(-1)
             for l in range(self.cfg.n_levels):
                 a, b = self.level_slice(l)

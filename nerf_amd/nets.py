@@ -390,7 +390,8 @@ class NeRFNetwork(nn.Module):
         return self.level_sharding
 
     def _sharded(self):
-        return self.level_sharding is not None and self.level_sharding.world > 1 and self._local_table == 0
+        sh = self.level_sharding
+        return sh is not None and (sh.world > 1 or sh.force) and self._local_table == 0
 
     def sync_table(self):
         if self.level_sharding is not None:

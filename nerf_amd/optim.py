@@ -103,6 +103,7 @@ class FusedAdam(torch.optim.Optimizer):
                             and os.environ.get('NERF_TABLE_PARALLEL', '1') != '0')
         if shard_levels:
             sh = model.shard_levels(None if shard_levels is True else shard_levels)
+            sh.force = True         # explicitly requested (or world > 1): also valid, if pointless, for one rank
             self._sharding = sh
             model.table_pipeline = TablePipeline(model.encoder.cfg, model.encoder.cfg.n_features, levels=sh.mine,
                                                  reduce=False)

@@ -16,12 +16,13 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
-    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun)."""
+def init_from_env(backend=None, force=False):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun).  A world of one
+    rank gets no process group unless `force` (every helper below is a no-op without one)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
@@ -71,7 +72,7 @@ def all_reduce_grads(params, async_op=False, skip=()):
     """SUM-all-reduce the .grad of every parameter (largest first so the big transfer starts early).
     `skip`: parameters whose gradient is reduced elsewhere (the pipelined hash table).
     Returns the list of work handles when async_op."""
-    if world_size() == 1:
+    if not dist.is_initialized():
         return []
     handles = []
     skip_ids = {id(p) for p in skip}
@@ -97,7 +98,7 @@ def all_reduce_grads(params, async_op=False, skip=()):
 def gather_slices(local, total, dim=0):
     """all_gather contiguous slices produced with shard_range back into one tensor of length `total`."""
     world = world_size()
-    if world == 1:
+    if not dist.is_initialized():
         return local
     sizes = [shard_range(total, r, world) for r in range(world)]
     maxlen = max(b - a for a, b in sizes)
@@ -124,7 +125,7 @@ def _all_gather_list(t):
 def gather_varlen(local):
     """all_gather of [P_r, C] tensors with per-rank row counts (dense extraction results)."""
     world = world_size()
-    if world == 1:
+    if not dist.is_initialized():
         return local
     count = torch.tensor([local.shape[0]], device=local.device, dtype=torch.int64)
     counts = [int(c.item()) for c in _all_gather_list(count)]
@@ -143,7 +144,7 @@ def _stage_cpu(t):
 def all_gather_rows(local):
     """[R, ...] on every rank -> [world*R, ...], rank-major (equal R on all ranks)."""
     world = world_size()
-    if world == 1:
+    if not dist.is_initialized():
         return local
     local = local.contiguous()
     if _stage_cpu(local):
@@ -182,7 +183,7 @@ def all_to_all_blocks(recv_blocks, send_blocks, async_op=False):
 
 def broadcast_(t, src):
     """In-place broadcast of a (contiguous view of a) tensor from rank `src`."""
-    if world_size() == 1:
+    if not dist.is_initialized():
         return t
     if _stage_cpu(t):
         c = t.cpu()
