@@ -30,31 +30,36 @@ from . import parallel
 from ._lib import NerfColMap, NerfLevelSet, check, lib, ptr, stream
 
 
-def level_costs(cfg):
-    """Relative per-level cost of owning a level (encode gathers + scatter atomics + Adam on it), from
-    tools/shard_emulate.py --per-level on MI355X (profiles/r01_shard_emulate_w8.log): a level's scatter runs at the
-    memory-side atomic rate whatever its size (~0.9 ms for 4.2 M points), except for the small dense levels that
-    the LDS-privatised kernel handles; the gathers of both passes add 0.05 (dense, L2-resident) to 0.5 (finest
-    hashed level)."""
+def level_costs(cfg, world=8):
+    """Cost (ms per step, MI355X, 4096 rays x 128 samples per rank) of owning a level in a world of `world` ranks,
+    from tools/shard_emulate.py --per-level (profiles/r01_shard_emulate_w8.log):
+
+        scatter  grows with the points of ALL ranks: 0.11 ms per 524 k points at the memory-side atomic rate whatever
+                 the level's size, 0.13 on the big dense levels (more same-line traffic), 0.044 on the small dense
+                 levels that the LDS-privatised kernel takes;
+        encode   (coarse + fine pass = 1.5 x the fine pass) likewise: 0.005 ms (L2-resident dense level) to 0.04 ms
+                 (finest hashed level) per 524 k points;
+        Adam     does not grow with the world: 32 B per float of the level at ~5.4 TB/s (0.2 ms for a hashed level).
+    """
     out = []
     hashed = [l for l in range(cfg.n_levels) if cfg.hashed[l]]
     for l in range(cfg.n_levels):
         floats = cfg.entries[l] * cfg.n_features
         if cfg.hashed[l]:
-            out.append(1.15 + 0.25 * (l - hashed[0]) / max(1, len(hashed) - 1))
-        elif floats <= 2 * 32768:
-            out.append(0.4)
-        elif floats <= 16 * 32768:
-            out.append(0.95)
+            scatter = 0.112
+            encode = 0.019 + 0.021 * (l - hashed[0]) / max(1, len(hashed) - 1)
         else:
-            out.append(1.1)
+            scatter = 0.044 if floats <= 2 * 32768 else (0.11 if floats <= 16 * 32768 else 0.13)
+            encode = 0.005 + 0.007 * min(1.0, cfg.entries[l] / float(1 << 24))
+        adam = floats * 32 / 5.4e9
+        out.append(world * (scatter + 1.5 * encode) + adam)
     return out
 
 
 def assign_levels(cfg, world):
     """owner[l] for every level: longest-processing-time greedy on level_costs, then moves / swaps while they
     lower the sum of squared loads (deterministic; identical on every rank)."""
-    cost = level_costs(cfg)
+    cost = level_costs(cfg, world)
     L = cfg.n_levels
     load = [0.0] * world
     owner = [0] * L

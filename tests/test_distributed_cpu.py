@@ -152,7 +152,7 @@ def test_assign_levels_covers_and_balances():
     for world in (1, 2, 3, 4, 8):
         owner = assign_levels(cfg, world)
         assert len(owner) == 20 and set(owner) <= set(range(world))
-        cost = level_costs(cfg)
+        cost = level_costs(cfg, world)
         load = [sum(c for c, o in zip(cost, owner) if o == r) for r in range(world)]
         assert max(load) - min(load) <= max(cost) + 1e-9       # LPT bound
 

@@ -128,7 +128,7 @@ def main():
         C.byref(src_l), ptr(xh), ptr(sig), ptr(rgb), None, stream()), 'f'))
     out['mlp_ms'] = {k: round(x, 4) for k, x in mlp.items()}
     tot = [t['total_table_ms'] for t in ranks]
-    out.update(world=W, owner=LevelSharding(cfg, 'cuda', owner=owner, rank=0, world=W).owner, costs=level_costs(cfg),
+    out.update(world=W, owner=LevelSharding(cfg, 'cuda', owner=owner, rank=0, world=W).owner, costs=level_costs(cfg, W),
                max_table_ms=max(tot), mean_table_ms=sum(tot) / W)
     print(json.dumps(out))
 
