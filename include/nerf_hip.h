@@ -116,6 +116,12 @@ int nerf_sh_fwd(const float* d01 /*[M,3] in [0,1]*/, int64_t n_points, int degre
 int nerf_mlp_fwd(const float* params, const int32_t* dims, int n_layers, const float* x, int64_t n_rows, float* out,
                  void* stream);
 
+/* Backward of nerf_mlp_fwd (what autograd + tcnn.Network do when the two networks are called as separate modules).
+ * dparams is ACCUMULATED into; dx [n_rows, dims[0]] is nullable; workspace: nerf_mlp_bwd_workspace_floats floats. */
+int64_t nerf_mlp_bwd_workspace_floats(const int32_t* dims, int n_layers, int64_t n_rows);
+int nerf_mlp_bwd(const float* params, const int32_t* dims, int n_layers, const float* x, const float* dout, int64_t n_rows,
+                 float* dx, float* dparams, float* workspace, int64_t workspace_floats, void* stream);
+
 /* ---- fused field network ---- */
 /* NeRFNetwork.density (nets.py:148-164): normalise, hash-grid encode, sigma MLP, relu. */
 int nerf_density_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const float* table, const float* sigma_params,

@@ -1,0 +1,135 @@
+// Stand-alone bias-free MLP backward: what autograd + tcnn.Network deliver when the reference's two networks are
+// called as separate modules (nets.py:120,135,155).  NOT the hot path -- training goes through the fused field
+// kernels -- but it completes the tinycudann-level boundary (Encoding fwd/bwd, Network fwd/bwd) for a maintainer who
+// keeps the reference's own nets.py.  Plain, layer-by-layer, caller-provided workspace:
+//   acts   [layer 1..n][rows][dims[layer]]   post-activation outputs of every layer (forward pass, recomputed here)
+//   dz, g0, g1 [rows][128] each              dz of the current layer, ping-pong buffers for the gradient passed down
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxW = 128;
+struct Dims9 { int v[9]; };
+
+// one thread per row: forward through every layer, keeping all activations
+__global__ void mlp_acts_kernel(const float* __restrict__ params, Dims9 d, int n_layers, const float* __restrict__ x,
+                                int64_t rows, float* __restrict__ acts) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float* in = x + r * d.v[0];
+    const float* w = params;
+    float* out = acts;
+    for (int l = 0; l < n_layers; ++l) {
+        const int ni = d.v[l], no = d.v[l + 1];
+        float* o = out + r * no;
+        for (int j = 0; j < no; ++j) {
+            float acc = 0.f;
+            for (int k = 0; k < ni; ++k) acc = fmaf(w[j * ni + k], in[k], acc);
+            o[j] = (l + 1 < n_layers) ? fmaxf(acc, 0.f) : acc;
+        }
+        in = o;
+        w += ni * no;
+        out += rows * no;
+    }
+}
+
+// dz = dout * relu'(act) (hidden layers), dh = dz * W   -- one thread per row
+__global__ void mlp_bwd_layer_kernel(const float* __restrict__ w, int ni, int no, int is_last, const float* __restrict__ act,
+                                     const float* __restrict__ dout, int64_t rows, float* __restrict__ dz,
+                                     float* __restrict__ dh) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    float z[kMaxW];
+    for (int j = 0; j < no; ++j) {
+        const float g = dout[r * no + j];
+        z[j] = (is_last || act[r * no + j] > 0.f) ? g : 0.f;
+        dz[r * no + j] = z[j];
+    }
+    if (!dh) return;
+    for (int k = 0; k < ni; ++k) {
+        float acc = 0.f;
+        for (int j = 0; j < no; ++j) acc = fmaf(z[j], w[j * ni + k], acc);
+        dh[r * ni + k] = acc;
+    }
+}
+
+// dW[o][i] += sum_r dz[r][o] * h[r][i]: 16x16 threads own a 16x16 tile of dW, blockIdx.z walks row chunks
+constexpr int kChunk = 2048;
+__global__ __launch_bounds__(256) void mlp_dw_kernel(const float* __restrict__ dz, const float* __restrict__ h, int ni,
+                                                     int no, int64_t rows, float* __restrict__ dw) {
+    __shared__ float sz[64][17], sh[64][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int o0 = blockIdx.y * 16, i0 = blockIdx.x * 16;
+    const int64_t r0 = (int64_t)blockIdx.z * kChunk;
+    const int64_t r1 = r0 + kChunk < rows ? r0 + kChunk : rows;
+    float acc = 0.f;
+    for (int64_t base = r0; base < r1; base += 64) {
+        for (int t = threadIdx.x; t < 64 * 16; t += 256) {
+            const int rr = t >> 4, c = t & 15;
+            const int64_t r = base + rr;
+            sz[rr][c] = (r < r1 && o0 + c < no) ? dz[r * no + o0 + c] : 0.f;
+            sh[rr][c] = (r < r1 && i0 + c < ni) ? h[r * ni + i0 + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int rr = 0; rr < 64; ++rr) acc = fmaf(sz[rr][ty], sh[rr][tx], acc);
+        __syncthreads();
+    }
+    if (o0 + ty < no && i0 + tx < ni) atomicAdd(dw + (o0 + ty) * ni + i0 + tx, acc);
+}
+
+int check_dims(const int32_t* dims, int n_layers) {
+    if (!dims || n_layers < 1 || n_layers > 8) return 1;
+    for (int i = 0; i <= n_layers; ++i)
+        if (dims[i] < 1 || dims[i] > kMaxW) return 1;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int64_t nerf_mlp_bwd_workspace_floats(const int32_t* dims, int n_layers, int64_t n_rows) {
+    if (check_dims(dims, n_layers) || n_rows < 0) return -1;
+    int64_t f = 0;
+    for (int l = 1; l <= n_layers; ++l) f += n_rows * dims[l];
+    return f + 3 * n_rows * kMaxW;
+}
+
+extern "C" int nerf_mlp_bwd(const float* params, const int32_t* dims, int n_layers, const float* x, const float* dout,
+                            int64_t n_rows, float* dx, float* dparams, float* workspace, int64_t workspace_floats,
+                            void* stream) {
+    NERF_REQUIRE(params && x && dout && dparams && workspace, "null pointer");
+    NERF_REQUIRE(!check_dims(dims, n_layers) && n_rows >= 0, "layer widths must be in [1,128], 1..8 layers");
+    NERF_REQUIRE(workspace_floats >= nerf_mlp_bwd_workspace_floats(dims, n_layers, n_rows), "workspace too small");
+    if (n_rows == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    Dims9 d = {};
+    for (int i = 0; i <= n_layers; ++i) d.v[i] = dims[i];
+    float* acts = workspace;
+    int64_t acts_floats = 0;
+    for (int l = 1; l <= n_layers; ++l) acts_floats += n_rows * dims[l];
+    float* dz = workspace + acts_floats;
+    float* g[2] = {dz + n_rows * kMaxW, dz + 2 * n_rows * kMaxW};
+    const unsigned nb = (unsigned)ceil_div64(n_rows, 64);
+    mlp_acts_kernel<<<nb, 64, 0, st>>>(params, d, n_layers, x, n_rows, acts);
+    int64_t w_off[9], a_off[9];       // offsets of every layer's weights / activations
+    int64_t wo = 0, ao = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        w_off[l] = wo; a_off[l] = ao;
+        wo += (int64_t)dims[l] * dims[l + 1];
+        ao += n_rows * dims[l + 1];
+    }
+    const float* grad_in = dout;
+    int cur = 0;
+    for (int l = n_layers - 1; l >= 0; --l) {
+        const int ni = dims[l], no = dims[l + 1];
+        float* dh_l = (l == 0) ? dx : g[cur];             // dx nullable: the input gradient is optional
+        mlp_bwd_layer_kernel<<<nb, 64, 0, st>>>(params + w_off[l], ni, no, l == n_layers - 1, acts + a_off[l], grad_in, n_rows,
+                                                dz, dh_l);
+        const float* h = (l == 0) ? x : acts + a_off[l - 1];
+        const dim3 grid((unsigned)((ni + 15) / 16), (unsigned)((no + 15) / 16), (unsigned)ceil_div64(n_rows, kChunk));
+        mlp_dw_kernel<<<grid, 256, 0, st>>>(dz, h, ni, no, n_rows, dparams + w_off[l]);
+        grad_in = dh_l;
+        cur ^= 1;
+    }
+    return nerf_launch_status("nerf_mlp_bwd");
+}

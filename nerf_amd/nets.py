@@ -110,28 +110,39 @@ class FullyFusedMLP(nn.Module):
             chunks.append((torch.rand(o * n, generator=g) * 2 - 1) * bound)
         self.params = nn.Parameter(torch.cat(chunks).to(device))
 
-    @torch.no_grad()
     def forward(self, x):
-        """Stand-alone inference call (the training path goes through the fused field kernels)."""
-        xx = f32(x).reshape(-1, self.n_input_dims)
-        out = torch.empty(xx.shape[0], self.n_output_dims, device=xx.device, dtype=torch.float32)
-        dims = (C.c_int32 * len(self.widths))(*self.widths)
-        check(lib().nerf_mlp_fwd(ptr(self.params), dims, len(self.widths) - 1, ptr(xx), xx.shape[0], ptr(out), stream()),
+        """Stand-alone call with autograd (the training hot path goes through the fused field kernels instead)."""
+        return _MLPFn.apply(x, self.params, self)
+
+
+class _MLPFn(torch.autograd.Function):
+    """tcnn.Network as a module of its own: nerf_mlp_fwd / nerf_mlp_bwd."""
+
+    @staticmethod
+    def forward(ctx, x, params, mod):
+        xx = f32(x).reshape(-1, mod.n_input_dims)
+        out = torch.empty(xx.shape[0], mod.n_output_dims, device=xx.device, dtype=torch.float32)
+        dims = (C.c_int32 * len(mod.widths))(*mod.widths)
+        check(lib().nerf_mlp_fwd(ptr(params), dims, len(mod.widths) - 1, ptr(xx), xx.shape[0], ptr(out), stream()),
               'nerf_mlp_fwd')
-        return out.reshape(*x.shape[:-1], self.n_output_dims)
+        ctx.save_for_backward(xx, params)
+        ctx.mod, ctx.in_shape, ctx.need_dx = mod, x.shape, x.requires_grad
+        return out.reshape(*x.shape[:-1], mod.n_output_dims)
 
-
-def _slice_src_kwargs(kw, a, b, unit):
-    """make_point_src kwargs restricted to rays [a, b) (mode 1) or points [a, b) (mode 0, unit = 1)."""
-    out = dict(kw)
-    if kw.get('x') is not None:
-        out.update(x=kw['x'][a:b], d=kw['d'][a:b] if kw.get('d') is not None else None,
-                   n=kw['n'][a:b] if kw.get('n') is not None else None, n_points=b - a)
-        return out
-    zs = kw.get('z_stride', 0)
-    out.update(rays_o=kw['rays_o'][a:b], rays_d=kw['rays_d'][a:b], z=kw['z'] if zs == 0 else kw['z'][a:b],
-               n=kw['n'][a:b] if kw.get('n') is not None else None, n_points=(b - a) * unit)
-    return out
+    @staticmethod
+    def backward(ctx, dout):
+        xx, params = ctx.saved_tensors
+        mod = ctx.mod
+        rows = xx.shape[0]
+        dims = (C.c_int32 * len(mod.widths))(*mod.widths)
+        n_ws = lib().nerf_mlp_bwd_workspace_floats(dims, len(mod.widths) - 1, rows)
+        ws = torch.empty(max(int(n_ws), 1), device=xx.device, dtype=torch.float32)
+        dparams = torch.zeros_like(params)
+        dx = torch.empty_like(xx) if ctx.need_dx else None
+        d = f32(dout).reshape(rows, mod.n_output_dims)
+        check(lib().nerf_mlp_bwd(ptr(params), dims, len(mod.widths) - 1, ptr(xx), ptr(d), rows, ptr(dx), ptr(dparams), ptr(ws),
+                                 ws.numel(), stream()), 'nerf_mlp_bwd')
+        return (dx.reshape(ctx.in_shape) if dx is not None else None), dparams, None
 
 
 class _FieldFn(torch.autograd.Function):

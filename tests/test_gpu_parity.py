@@ -385,3 +385,51 @@ def test_chunked_backward_matches_unchunked():
         # Adam divides by sqrt(v): entries whose gradient is ~0 amplify summation-order noise to +-lr
         torch.testing.assert_close(g, w, rtol=0, atol=2e-3 * 40, msg=lambda m, n=name: n + ': ' + m)
         assert float(((g - w).abs() > 1e-4).float().mean()) < 0.02, name
+
+
+def test_module_level_composition_matches_fused_field():
+    """The tinycudann-level boundary: encoder / sigma_net / encoder_dir / color_net called as separate modules and
+    glued with torch ops exactly as the reference's nets.py:109-146 does, forward and backward, against the fused
+    field kernels (nerf_hashgrid_fwd/bwd, nerf_sh_fwd, nerf_mlp_fwd/bwd vs nerf_field_fwd/bwd)."""
+    import torch.nn.functional as F
+    net, _ = _make_pair(NET_CFGS['small'])
+    g = torch.Generator().manual_seed(31)
+    M, ob = 777, 2.5
+    x = ((torch.rand(M, 3, generator=g) * 2 - 1) * 2.4).cuda()
+    d = torch.randn(M, 3, generator=g)
+    d = (d / d.norm(dim=-1, keepdim=True)).cuda()
+    n = torch.randint(0, 7, (M,), generator=g).cuda()
+    gs, gc = torch.randn(M, generator=g).cuda(), torch.randn(M, 3, generator=g).cuda()
+    params = [net.encoder.params, net.sigma_net.params, net.color_net.params, net.latent_emb]
+
+    def grads(fn):
+        for p in params:
+            p.grad = None
+        sigma, color = fn()
+        ((sigma * gs).sum() + (color * gc).sum()).backward()
+        return sigma.detach(), color.detach(), [p.grad.detach().clone() for p in params]
+
+    def modules():                                      # nets.py:109-146, line by line
+        xx = (x + ob) / (2 * ob)
+        x_hashtable = net.encoder(xx)
+        sigma_out = net.sigma_net(x_hashtable)
+        sigma = F.relu(sigma_out[..., 0])
+        geo_feat = sigma_out[..., 1:]
+        dd = net.encoder_dir((d + 1) / 2)
+        color_in = torch.cat([geo_feat, dd, net.latent_emb[n]], dim=-1)
+        color = torch.sigmoid(net.color_net(color_in))
+        return sigma, color
+
+    def fused():
+        sigma, color, _ = net(x, d, n, ob)
+        return sigma, color
+    s_m, c_m, g_m = grads(modules)
+    s_f, c_f, g_f = grads(fused)
+    scale = float(s_f.abs().max()) + 1e-6
+    torch.testing.assert_close(s_m, s_f, rtol=1e-4, atol=1e-5 * scale)
+    torch.testing.assert_close(c_m, c_f, rtol=0, atol=1e-5)
+    for a, b, name in zip(g_m, g_f, ('table', 'sigma_net', 'color_net', 'latent')):
+        s = float(b.abs().max()) + 1e-12
+        torch.testing.assert_close(a, b, rtol=1e-3, atol=2e-5 * s, msg=lambda m, w=name: w + ': ' + m)
+    for p in params:
+        p.grad = None
