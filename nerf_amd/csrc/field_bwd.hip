@@ -60,6 +60,17 @@ __device__ __forceinline__ void flush_tile(float* __restrict__ dw, const f32x16&
     }
 }
 
+// Sum over the 32 lanes of each wave half, result in every lane.  Four rotate-and-add steps inside the 16-lane DPP rows
+// (plain VALU, no LDS crossbar) and one cross-row exchange; the __shfl_xor ladder this replaces cost 5 ds_bpermute
+// round trips per value (9.5 k cycles per tile for the 24 latent gradients).
+__device__ __forceinline__ float half_sum32(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));  // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));  // row_ror:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));  // row_ror:1
+    return v + __shfl_xor(v, 16, kWave);
+}
+
 __device__ __forceinline__ f32x16 relu_mask(const f32x16& d, const f32x16& act) {
     f32x16 r;
 #pragma unroll
@@ -231,17 +242,13 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
             if (uniform) {
 #pragma unroll
                 for (int t = 8; t < 16; ++t) {
-                    float v = dG[t];
-#pragma unroll
-                    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+                    const float v = half_sum32(dG[t]);
                     const int li = krow(t) + 4 * h - 16;
                     if (l31 == 0 && li < s.lat) atomicAdd(dlatent + n0 * s.lat + li, v);
                 }
 #pragma unroll
                 for (int t = 0; t < 16; ++t) {
-                    float v = dL[t];
-#pragma unroll
-                    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+                    const float v = half_sum32(dL[t]);
                     const int li = 16 + krow(t) + 4 * h;
                     if (l31 == 0 && li < s.lat) atomicAdd(dlatent + n0 * s.lat + li, v);
                 }

@@ -145,6 +145,19 @@ class _MLPFn(torch.autograd.Function):
         return (dx.reshape(ctx.in_shape) if dx is not None else None), dparams, None
 
 
+def _slice_src_kwargs(kw, a, b, unit):
+    """make_point_src kwargs restricted to rays [a, b) (mode 1) or points [a, b) (mode 0, unit = 1)."""
+    out = dict(kw)
+    if kw.get('x') is not None:
+        out.update(x=kw['x'][a:b], d=kw['d'][a:b] if kw.get('d') is not None else None,
+                   n=kw['n'][a:b] if kw.get('n') is not None else None, n_points=b - a)
+        return out
+    zs = kw.get('z_stride', 0)
+    out.update(rays_o=kw['rays_o'][a:b], rays_d=kw['rays_d'][a:b], z=kw['z'] if zs == 0 else kw['z'][a:b],
+               n=kw['n'][a:b] if kw.get('n') is not None else None, n_points=(b - a) * unit)
+    return out
+
+
 class _FieldFn(torch.autograd.Function):
     """sigma, rgb = field(points); backward = nerf_field_bwd (gradients for table, MLPs, latent)."""
 
