@@ -71,6 +71,23 @@ __device__ __forceinline__ float half_sum32(float v) {
     return v + __shfl_xor(v, 16, kWave);
 }
 
+// this lane's half row of hash-grid features: 16-byte loads when the layout allows (`vec`), else guarded scalars
+template <int XF>
+__device__ __forceinline__ void load_features(float (&xf)[XF], const float* __restrict__ xrow, int LHF, int LF, int h, bool vec) {
+    if (vec) {
+        const f32x4* x4 = (const f32x4*)xrow;
+#pragma unroll
+        for (int qd = 0; qd < XF / 4; ++qd) {
+            const f32x4 v = x4[qd];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xf[4 * qd + e] = v[e];
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < XF; ++t) xf[t] = (t < LHF && h * LHF + t < LF) ? xrow[t] : 0.f;
+    }
+}
+
 __device__ __forceinline__ f32x16 relu_mask(const f32x16& d, const f32x16& act) {
     f32x16 r;
 #pragma unroll
@@ -98,6 +115,8 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
     const int64_t n_btiles = (M + kBlockPts - 1) / kBlockPts;
     const int LF = g.L * F, LHF = g.LH * F;
     const int in_c_tiles = (s.in_c + 31) / 32;
+    // every lane's half row of features / feature gradients is XF contiguous, 16-byte aligned floats (config_base: 20)
+    const bool vec = (XF % 4 == 0) && LHF == XF && LF == 2 * XF;
 
     // persistent dW accumulators (roles depend on the wave, see the file comment)
     f32x16 acc_s1 = zero16(), acc_c2 = zero16(), acc_c1 = zero16(), acc_x = zero16(), acc_y = zero16();
@@ -120,8 +139,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
         const float* xrow = xh + p * LF + h * LHF;
         const float* lrow = latent + q.n * s.lat + h * s.lat_half;
         float xf[XF], lat[24];
-#pragma unroll
-        for (int t = 0; t < XF; ++t) xf[t] = (t < LHF && h * LHF + t < LF) ? xrow[t] : 0.f;
+        load_features<XF>(xf, xrow, LHF, LF, h, vec);
 #pragma unroll
         for (int t = 0; t < 24; ++t) lat[t] = t < s.lat_half ? lrow[t] : 0.f;
         // ------------------------- forward recompute -------------------------
@@ -276,8 +294,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
         stage64(SB, col, h, a0, a1);
         __syncthreads();
         float xf2[XF];
-#pragma unroll
-        for (int t = 0; t < XF; ++t) xf2[t] = (t < LHF && h * LHF + t < LF) ? xrow[t] : 0.f;
+        load_features<XF>(xf2, xrow, LHF, LF, h, vec);
         if (wave < 2) acc_y = dw_tile(acc_y, SA, SB, 0, wave, kGeoRows, kHid, l31, h);
         layer_T_Nx64<8, kPS2>(lds + kWS2, kGeoRows, l31, h, d2, g0, g1);
         g0 = relu_mask(g0, a0);
@@ -312,10 +329,21 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
         // atomic-bound launch with its own lane mapping (see scatter_kernel in field_fwd.hip)
         if (valid) {
             float* dst = dfeat + p * LF + h * LHF;
+            if (vec) {      // this lane's LHF gradients are 16-byte aligned and contiguous: 16-byte stores
+                f32x4* d4 = (f32x4*)dst;
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                if (t < LHF && h * LHF + t < LF) dst[t] = x0[t];
-                if (16 + t < LHF && h * LHF + 16 + t < LF) dst[16 + t] = x1[t];
+                for (int qd = 0; qd < XF / 4; ++qd) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (4 * qd + e < 16) ? x0[(4 * qd + e) & 15] : x1[(4 * qd + e - 16) & 15];
+                    d4[qd] = v;
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    if (t < LHF && h * LHF + t < LF) dst[t] = x0[t];
+                    if (16 + t < LHF && h * LHF + 16 + t < LF) dst[16 + t] = x1[t];
+                }
             }
         }
     }
