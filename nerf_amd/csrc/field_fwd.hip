@@ -49,8 +49,9 @@ __global__ __launch_bounds__(256) void field_fwd_kernel(GridDev g, NetLds s, con
             float feat[F];
             if (FEATS) {
                 const float* fsrc = xh_in + p * LF + (lp.active ? h * g.LH + j : 0) * F;
-#pragma unroll
-                for (int f = 0; f < F; ++f) feat[f] = fsrc[f];
+                if (F == 2) { const f32x2 t = *(const f32x2*)fsrc; feat[0] = t.x; feat[F - 1] = t.y; }
+                else if (F == 4) { const f32x4 t = *(const f32x4*)fsrc; feat[0] = t.x; feat[1 % F] = t.y; feat[2 % F] = t.z; feat[3 % F] = t.w; }
+                else feat[0] = fsrc[0];
             } else {
                 const Corners c = level_corners(lp, q.x, q.y, q.z);
                 gather_level<F>(table, c, feat);
@@ -63,8 +64,9 @@ __global__ __launch_bounds__(256) void field_fwd_kernel(GridDev g, NetLds s, con
             }
             if (!FEATS && xh_out && valid && lp.active) {
                 float* dst = xh_out + p * LF + (h * g.LH + j) * F;
-#pragma unroll
-                for (int f = 0; f < F; ++f) dst[f] = feat[f];
+                if (F == 2) { f32x2 t; t.x = feat[0]; t.y = feat[F - 1]; *(f32x2*)dst = t; }
+                else if (F == 4) { f32x4 t; t.x = feat[0]; t.y = feat[1 % F]; t.z = feat[2 % F]; t.w = feat[3 % F]; *(f32x4*)dst = t; }
+                else dst[0] = feat[0];
             }
         }
         a0 = relu16(a0);
