@@ -140,8 +140,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
         const float* lrow = latent + q.n * s.lat + h * s.lat_half;
         float xf[XF], lat[24];
         load_features<XF>(xf, xrow, LHF, LF, h, vec);
-#pragma unroll
-        for (int t = 0; t < 24; ++t) lat[t] = t < s.lat_half ? lrow[t] : 0.f;
+        load_latent_half(lat, lrow, s.lat_half);
         // ------------------------- forward recompute -------------------------
         f32x16 a0, a1;
         {
@@ -197,8 +196,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
         stage64(SB, col, h, c0, c1);
         __syncthreads();
         float lat2[24];
-#pragma unroll
-        for (int t = 0; t < 24; ++t) lat2[t] = t < s.lat_half ? lrow[t] : 0.f;   // lands under the dW MFMAs below
+        load_latent_half(lat2, lrow, s.lat_half);      // lands under the dW MFMAs below
         acc_c2 = dw_tile(acc_c2, SA, SB, wave >> 1, wave & 1, kHid, kHid, l31, h);
         {
             f32x16 t0, t1;

@@ -164,6 +164,23 @@ __device__ __forceinline__ PointIn fetch_point(const NerfPointSrc& s, int64_t p,
     return q;
 }
 
+// this lane's half of the latent row (up to 24 floats, zero padded): 16-byte loads when the half row is a whole
+// number of 16-byte quads at a 16-byte aligned offset (latent 48: 24 floats = 6 quads), else guarded scalars
+__device__ __forceinline__ void load_latent_half(float (&lat)[24], const float* __restrict__ lrow, int lat_half) {
+    if (lat_half == 24 && (((uintptr_t)lrow) & 15) == 0) {
+        const f32x4* l4 = (const f32x4*)lrow;
+#pragma unroll
+        for (int qd = 0; qd < 6; ++qd) {
+            const f32x4 v = l4[qd];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) lat[4 * qd + e] = v[e];
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 24; ++t) lat[t] = t < lat_half ? lrow[t] : 0.f;
+    }
+}
+
 struct LevelP {
     float scale;
     uint32_t res, entries, hashed, offset;

@@ -36,8 +36,7 @@ __global__ __launch_bounds__(256) void field_fwd_kernel(GridDev g, NetLds s, con
         float lat[24];   // this lane's half of the latent row, fetched under the hash-grid gathers
         if (COLOR) {
             const float* lrow = latent + q.n * s.lat + h * s.lat_half;
-#pragma unroll
-            for (int t = 0; t < 24; ++t) lat[t] = t < s.lat_half ? lrow[t] : 0.f;
+            load_latent_half(lat, lrow, s.lat_half);
         }
 
         // ---- sigma layer 1: encode a level, feed its F features as the next F k-steps ----
@@ -135,8 +134,12 @@ __global__ __launch_bounds__(256) void encode_levels_kernel(GridDev g, const flo
     const Corners c = level_corners(lp, q.x, q.y, q.z);
     float feat[F];
     gather_level<F>(table, c, feat);
+    float* dst = out + p * stride + slot * F;
+    if (F == 2 && !(stride & 1) && !(((uintptr_t)out) & 7)) { f32x2 t; t.x = feat[0]; t.y = feat[F - 1]; *(f32x2*)dst = t; }
+    else {
 #pragma unroll
-    for (int f = 0; f < F; ++f) out[p * stride + slot * F + f] = feat[f];
+        for (int f = 0; f < F; ++f) dst[f] = feat[f];
+    }
 }
 
 // Hash-table gradient scatter.  fp32 atomics execute at the memory side at a fixed rate of 64-byte
