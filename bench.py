@@ -137,7 +137,67 @@ def cpu_baseline(n_rays=1024, steps=2, threads=16):
                       % (steps, n_rays), 'seconds_per_step': t}
 
 
+def _beat():
+    """Tell the supervisor (if any) that this worker is alive."""
+    hb = os.environ.get('NERF_BENCH_HEARTBEAT')
+    if hb:
+        with open(hb, 'w') as f:
+            f.write(str(time.time()))
+
+
+def supervise(argv):
+    """N > 1 under torch.distributed.run: every launched rank process becomes a supervisor that never touches the GPU
+    and runs the real rank as a child process (the worker).  The level-sharded exchange has only ever run over gloo and
+    over RCCL in a world of one rank (there is one GPU per test box): should its first multi-GPU run stall in a collective
+    instead of raising, every supervisor sees its worker's heartbeat stop, ends that worker (its own child, by PID) and
+    starts a second worker generation on the replicated table (dense all-reduce, the plainest RCCL path), which says so in
+    config.parallelism.  A worker that succeeds is simply passed through: same stdout, same exit code."""
+    import signal
+    import subprocess
+    import tempfile
+    stall_s = float(os.environ.get('NERF_BENCH_STALL_S', '150'))
+    first_s = float(os.environ.get('NERF_BENCH_FIRST_S', '420'))     # import torch on a fresh box + build + rendezvous
+    rank = int(os.environ.get('RANK', '0'))
+    attempts = [('sharded', {})]
+    if os.environ.get('NERF_TABLE_PARALLEL') != '0':
+        attempts.append(('replicated', {'NERF_TABLE_PARALLEL': '0'}))
+    rc = 1
+    for i, (mode, extra) in enumerate(attempts):
+        hb = os.path.join(tempfile.gettempdir(), 'nerf_bench_hb_%d_%d_%d' % (os.getpid(), rank, i))
+        env = dict(os.environ, NERF_BENCH_WORKER='1', NERF_BENCH_HEARTBEAT=hb, NERF_STORE_PREFIX='nerfgen%d' % i, **extra)
+        if i > 0:
+            env['NERF_BENCH_NOTE'] = ' [level-sharded worker generation stalled or failed; replicated table]'
+        child = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env)
+        started, last = time.time(), None
+        stalled = False
+        while child.poll() is None:
+            time.sleep(1.0)
+            try:
+                last = os.path.getmtime(hb)
+            except OSError:
+                pass
+            quiet = time.time() - (last if last is not None else started)
+            if quiet > (stall_s if last is not None else first_s):
+                stalled = True
+                sys.stderr.write('bench supervisor rank %d: %s worker silent for %.0f s, ending it\n' % (rank, mode, quiet))
+                child.send_signal(signal.SIGKILL)
+                child.wait()
+        try:
+            os.remove(hb)
+        except OSError:
+            pass
+        rc = child.returncode
+        if rc == 0 and not stalled:
+            return 0
+        sys.stderr.write('bench supervisor rank %d: %s worker ended with code %s\n' % (rank, mode, rc))
+        time.sleep(5.0)      # let the driver reclaim the killed worker's queues before the next generation starts
+    return rc if rc else 1
+
+
 def main():
+    if (int(os.environ.get('WORLD_SIZE', '1')) > 1 and os.environ.get('TORCHELASTIC_USE_AGENT_STORE') == 'True'
+            and os.environ.get('NERF_BENCH_WORKER') != '1' and os.environ.get('NERF_BENCH_SUPERVISE', '1') != '0'):
+        sys.exit(supervise(sys.argv[1:]))
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
@@ -156,8 +216,10 @@ def main():
         import faulthandler
         faulthandler.dump_traceback_later(args.hang_trace, repeat=True)
 
+    _beat()
     from nerf_amd import _lib, parallel
     rank, world, local = parallel.init_from_env()
+    _beat()
     if world != args.gpus and world > 1:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     device = torch.device('cuda', local if world > 1 else 0)
@@ -169,11 +231,14 @@ def main():
         STEPS[:] = [256, 128, 64, 32]
         Z_BOUNDS[:] = [0.1, 1, 10, 100, 1000]
     model, renderer, loader, opt = build_gpu(device, rank, args.rays, pipeline=not args.no_pipeline)
-    fallback_note = ''
+    _beat()
+    fallback_note = os.environ.get('NERF_BENCH_NOTE', '')
     if world > 1 and model.level_sharding is not None:
         # The level-sharded exchange has only ever run over gloo (one-GPU box); if its first step raises over RCCL --
         # an API-level error is raised on every rank alike -- fall back to the replicated table, and say so.
         try:
+            if os.environ.get('NERF_TEST_BENCH_STALL') == '1':      # tests: a collective that never completes
+                time.sleep(3600)
             train_step(model, renderer, loader, opt, args.rays, 0, world)
             torch.cuda.synchronize()
         except Exception as e:      # noqa: BLE001
@@ -189,11 +254,13 @@ def main():
         owned = sum(b - a for a, b in (model_sharded.level_slice(l) for l in model_sharded.mine))
         n_params = n_params - model.encoder.params.numel() + owned
 
+    _beat()
     for it in range(args.warmup):
         train_step(model, renderer, loader, opt, args.rays, it, world)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    _beat()
     t0 = time.perf_counter()
     for it in range(args.steps):
         train_step(model, renderer, loader, opt, args.rays, args.warmup + it, world)
@@ -208,6 +275,7 @@ def main():
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
     value = world * args.rays * args.steps / elapsed
+    _beat()
 
     # ---- per-kernel device times (live, HIP events on the launch stream) ----
     if args.profile_steps > 0:
@@ -215,6 +283,7 @@ def main():
     for it in range(args.profile_steps):
         train_step(model, renderer, loader, opt, args.rays, it, world)
     prof = _lib.kernel_timing(False) if args.profile_steps > 0 else {}
+    _beat()
     kernels = []
     n_pts_scatter = args.rays * SF * (world if model_sharded is not None else 1)
     pipe = model.table_pipeline
@@ -283,6 +352,7 @@ def main():
             inf.render_image(n, h, w, K, E)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t1) / reps
+        _beat()
         render = {'workload': '800x800 image, 64+128 samples/ray, chunks of 65536 rays, sharded over %d GPU(s)' % world,
                   'rays_per_s': H * W / dt, 'ms_per_image': dt * 1e3}
 
@@ -305,6 +375,9 @@ def main():
                                                                     if getattr(model_sharded, 'world', 1) > 1 else '') + fallback_note},
             'roofline': roofline, 'roofline_second': roofline_2, 'cpu_baseline': cpu, 'render': render, 'kernels': kernels,
         }
+    if world > 1:
+        dist.barrier()       # every rank got here: only now may rank 0 report
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -31,7 +31,16 @@ def init_from_env(backend=None, force=False):
         if torch.cuda.is_available():
             local = local % torch.cuda.device_count()
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        prefix = os.environ.get('NERF_STORE_PREFIX')
+        if prefix:
+            # a second generation of rank processes behind one launcher (bench.py's supervisor): same store as the
+            # launcher's, under a key prefix of its own so that nothing of an earlier generation is read back
+            from datetime import timedelta
+            store = dist.TCPStore(os.environ['MASTER_ADDR'], int(os.environ['MASTER_PORT']), world, False,
+                                  timedelta(seconds=600), wait_for_workers=False)
+            dist.init_process_group(backend=backend, store=dist.PrefixStore(prefix, store), rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
         if backend == 'nccl':
             # create the RCCL communicator now, on the main thread, instead of lazily inside the first
             # collective (which the training loop issues from autograd's backward thread)
