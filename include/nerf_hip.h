@@ -227,6 +227,26 @@ int nerf_losses(const float* image, const float* gt, const float* weights, const
 int nerf_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t count, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int64_t step, float grad_scale, int zero_grad, void* stream);
 
+/* ---- binned table update: tcnn HashGrid backward + torch.optim.Adam (train.py:84-88) on the hash table in one pass ----
+ * The same result as nerf_hashgrid_scatter_levels into a zeroed gradient followed by nerf_adam_step over the listed
+ * levels (up to the summation order of the corner contributions), without a gradient array: the step's corner updates
+ * are sorted into table partitions first (nerf_table_bin_levels: needs no optimizer hyper-parameters, so it can run
+ * inside the backward pass), then every partition is summed in LDS and updated in place (nerf_table_update_binned:
+ * 24 B of HBM traffic per parameter instead of 32 B, no memory-side atomics).  Levels must hold a multiple of 4 floats
+ * at a 16-byte offset and at most 8192 partitions of 16 K floats (NERF_EUNSUPPORTED otherwise); meant for the hashed
+ * and the large dense levels -- a level smaller than one partition works but serialises on one workgroup.
+ * The caller owns the workspace; it must stay untouched between the two calls. */
+int64_t nerf_table_bin_workspace_bytes(const NerfGridCfg* grid, const NerfLevelSet* levels, int64_t n_points); /* < 0: error */
+/* dfeat_by_level == 0: the F gradient columns of levels->level[i] start at column i*F of dfeat (as in
+ * nerf_hashgrid_scatter_levels); != 0: at column level*F (the full [M, L*F] matrix nerf_field_bwd writes). */
+int nerf_table_bin_levels(const NerfGridCfg* grid, const NerfPointSrc* src, const NerfLevelSet* levels, const float* dfeat,
+                          int64_t dfeat_stride, int dfeat_by_level, void* workspace, int64_t workspace_bytes, void* stream);
+/* table / exp_avg / exp_avg_sq: the WHOLE table's tensors (level offsets come from grid); only the listed levels change.
+ * n_points and levels must be those of the nerf_table_bin_levels call that filled the workspace. */
+int nerf_table_update_binned(const NerfGridCfg* grid, const NerfLevelSet* levels, int64_t n_points, const void* workspace,
+                             int64_t workspace_bytes, float* table, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int64_t step, float grad_scale, void* stream);
+
 /* ---- inference helpers: inference.py:97-105 ---- */
 int nerf_cum_weights_thresh(const float* weights, int64_t n_rays, int n_samples, float thresh, float* out, void* stream);
 

@@ -2,35 +2,9 @@
 // 16 B read + 12 B written per parameter (+4 B when the gradient is cleared in the same pass).
 // Same update rule as torch.optim.Adam's single-tensor path as configured at train.py:84-88
 // (L2 weight decay folded into the gradient, no amsgrad).
-#include "common.h"
+#include "adam_common.h"
 
 namespace {
-
-struct AdamK {
-    float lr_over_bc1;   // lr / (1 - beta1^t)
-    float inv_sqrt_bc2;  // 1 / sqrt(1 - beta2^t)
-    float beta1, beta2, one_m_beta1, one_m_beta2, eps, wd, gscale;
-};
-
-__device__ __forceinline__ void adam1(float& p, float& g, float& m, float& v, const AdamK& k) {
-    float gr = g * k.gscale;
-    if (k.wd != 0.f) gr = fmaf(k.wd, p, gr);
-    m = m + k.one_m_beta1 * (gr - m);                 // exp_avg.lerp_(grad, 1 - beta1)
-    v = fmaf(k.one_m_beta2 * gr, gr, v * k.beta2);    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-    const float denom = sqrtf(v) * k.inv_sqrt_bc2 + k.eps;
-    p = p - k.lr_over_bc1 * (m / denom);
-}
-
-typedef float f4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ void adam4(f4& p, const f4& g, f4& m, f4& v, const AdamK& k) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        float a = p[e], b = g[e], c = m[e], d = v[e];
-        adam1(a, b, c, d, k);
-        p[e] = a; m[e] = c; v[e] = d;
-    }
-}
 
 // Two independent 16-byte quads per lane in flight, non-temporal loads/stores (every byte is touched
 // exactly once per step, so nothing is worth keeping in L2 / Infinity Cache), and a grid of many
@@ -82,14 +56,7 @@ extern "C" int nerf_adam_step(float* param, float* grad, float* exp_avg, float* 
     NERF_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
                  "buffers must be 16-byte aligned");
     if (count == 0) return 0;
-    AdamK k;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-    k.lr_over_bc1 = (float)((double)lr / bc1);
-    k.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
-    k.beta1 = beta1; k.beta2 = beta2;
-    k.one_m_beta1 = (float)(1.0 - (double)beta1);
-    k.one_m_beta2 = (float)(1.0 - (double)beta2);
-    k.eps = eps; k.wd = weight_decay; k.gscale = grad_scale;
+    const AdamK k = make_adam_k(lr, beta1, beta2, eps, weight_decay, step, grad_scale);
     int64_t want = ceil_div64(ceil_div64(count, 8), 256);
     if (want < 1) want = 1;
     const unsigned nb = (unsigned)(want < 65536 ? want : 65536);

@@ -1,0 +1,349 @@
+// Binned hash-table update for gfx950: gradient scatter and Adam in ONE pass over the table.
+//
+// The classic pair -- atomic scatter of d(features) into a dense gradient array (tcnn HashGrid backward), then a
+// dense Adam pass (train.py:84-88) -- moves 32 B per table parameter through HBM (p, g, m, v read; p, m, v written;
+// g cleared) and pays the memory-side atomic rate for every corner update.  Here the corner updates of a step are
+// first BINNED by table partition (a counting sort: count, scan, fill -- no global atomics, a deterministic number of
+// items), then one workgroup per partition (16 K floats = 64 KB of LDS) sums its bin into LDS with ds_add_f32 and
+// streams p, m, v through the Adam update with the gradient read from LDS: 24 B per parameter, no gradient array,
+// no memory-side atomics.  The update rule is exactly nerf_adam_step's (adam_common.h); only the summation order of
+// the corner contributions differs (as it does between any two runs of the atomic scatter).
+//
+// Used for the levels that are large enough to fill many partitions (the hashed levels and the big dense ones); the
+// small dense levels keep the LDS-privatised scatter + nerf_adam_step (a level smaller than a partition would put
+// every item of the step into one bin).
+#include "adam_common.h"
+#include "field_common.h"
+
+int nerf_check_src(const char* fn, const NerfPointSrc* src, bool with_color);   // field_fwd.hip
+
+namespace {
+
+constexpr int kPartFloats = 16384;        // floats of one table partition (64 KB of LDS in the update kernel)
+#ifndef NERF_BIN_CHUNK
+#define NERF_BIN_CHUNK 16384
+#endif
+constexpr int kBinChunkPts = NERF_BIN_CHUNK;   // points per workgroup of the count / fill passes
+constexpr int kBinThreads = 1024;
+constexpr int kUpdThreads = 512;
+constexpr int kMaxBinsPerLevel = 8192;    // LDS histogram of the count / fill passes: 32 KB
+
+struct BinPlan {
+    int count;
+    int level[NERF_MAX_LEVELS];
+    int col[NERF_MAX_LEVELS];                    // first d(features) column of the level
+    uint32_t nbins[NERF_MAX_LEVELS];
+    uint32_t part_base[NERF_MAX_LEVELS + 1];     // running sum of nbins: workgroup id of the update kernel -> level slot
+    int64_t hist_off[NERF_MAX_LEVELS];           // in uint32 units: the slot's [bin][workgroup] histogram / offsets
+    int64_t item_off[NERF_MAX_LEVELS];           // in items: the slot's 8 * n_points items
+};
+
+// An item = one corner update = (float offset inside its partition: uint16, F gradient values), kept as two arrays.
+// (One 16-byte record per item halves the scattered store requests of the fill pass but was not faster, 0.79 vs
+// 0.84 ms for 63 M items, and the update kernel then reads 1.0 GB instead of 0.63 GB: 2.18 vs 2.07 ms.)
+struct BinLayout {       // byte offsets into the caller's workspace
+    int64_t hist, bin_start, item_idx, item_val, total;
+    int nwg;
+};
+
+__device__ __forceinline__ LevelP plan_level(const GridDev& g, int l) {
+    LevelP lp;
+    lp.scale = g.scale[l];
+    lp.res = g.res[l];
+    lp.entries = g.entries[l];
+    lp.hashed = g.hashed[l];
+    lp.offset = 0;          // level-relative entry indices
+    lp.active = true;
+    return lp;
+}
+
+// pass 1: per workgroup (a chunk of points of one level) the number of items that fall into every partition
+template <int F>
+__global__ __launch_bounds__(kBinThreads) void bin_count_kernel(GridDev g, NerfPointSrc src, BinPlan plan, int64_t M,
+                                                                int nwg, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t lh[kMaxBinsPerLevel];
+    const int slot = blockIdx.y, l = plan.level[slot];
+    const uint32_t nb = plan.nbins[slot];
+    for (uint32_t i = threadIdx.x; i < nb; i += kBinThreads) lh[i] = 0u;
+    __syncthreads();
+    const LevelP lp = plan_level(g, l);
+    const int64_t p0 = (int64_t)blockIdx.x * kBinChunkPts;
+    const int64_t p1 = p0 + kBinChunkPts < M ? p0 + kBinChunkPts : M;
+    for (int64_t p = p0 + threadIdx.x; p < p1; p += kBinThreads) {
+        const PointIn q = fetch_point(src, p, false);
+        const Corners c = level_corners(lp, q.x, q.y, q.z);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) atomicAdd(&lh[(c.idx[k] * (uint32_t)F) / kPartFloats], 1u);
+    }
+    __syncthreads();
+    uint32_t* dst = hist + plan.hist_off[slot] + blockIdx.x;
+    for (uint32_t i = threadIdx.x; i < nb; i += kBinThreads) dst[(int64_t)i * nwg] = lh[i];
+}
+
+// pass 2: turn a slot's [bin][workgroup] counts (in place) into where every workgroup writes its items of every
+// bin; bin_start[b] = first item of bin b, bin_start[nbins] = 8 * n_points.  One workgroup per slot, a thread per
+// bin (the nwg counts of a bin are contiguous), block scan of the bin totals in LDS.
+__global__ __launch_bounds__(kBinThreads) void bin_scan_kernel(BinPlan plan, int nwg, uint32_t* __restrict__ hist,
+                                                               uint32_t* __restrict__ bin_start) {
+    __shared__ uint32_t part[kBinThreads];
+    constexpr int kPer = kMaxBinsPerLevel / kBinThreads;        // bins per thread (consecutive)
+    const int slot = blockIdx.x;
+    const uint32_t nb = plan.nbins[slot];
+    uint32_t* h = hist + plan.hist_off[slot];
+    uint32_t* bs = bin_start + plan.part_base[slot] + slot;
+    uint32_t tot[kPer];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const uint32_t b = threadIdx.x * kPer + j;
+        uint32_t t = 0;
+        if (b < nb) for (int w = 0; w < nwg; ++w) t += h[(int64_t)b * nwg + w];
+        tot[j] = t;
+        sum += t;
+    }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < kBinThreads; off <<= 1) {      // Hillis-Steele inclusive scan of the per-thread sums
+        const uint32_t add = threadIdx.x >= (unsigned)off ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const uint32_t b = threadIdx.x * kPer + j;
+        if (b < nb) {
+            bs[b] = run;
+            uint32_t r = run;
+            for (int w = 0; w < nwg; ++w) { const uint32_t c = h[(int64_t)b * nwg + w]; h[(int64_t)b * nwg + w] = r; r += c; }
+        }
+        run += tot[j];
+    }
+    if (threadIdx.x == kBinThreads - 1) bs[nb] = part[kBinThreads - 1];
+}
+
+// pass 3: write every item (partition-local float offset, F gradient values) to its place in its bin
+template <int F>
+__global__ __launch_bounds__(kBinThreads) void bin_fill_kernel(GridDev g, NerfPointSrc src, BinPlan plan, int64_t M, int nwg,
+                                                               const uint32_t* __restrict__ offs,
+                                                               const float* __restrict__ dfeat, int64_t stride,
+                                                               uint16_t* __restrict__ item_idx, float* __restrict__ item_val) {
+    __shared__ uint32_t cur[kMaxBinsPerLevel];
+    const int slot = blockIdx.y, l = plan.level[slot];
+    const uint32_t nb = plan.nbins[slot];
+    const uint32_t* o = offs + plan.hist_off[slot] + blockIdx.x;
+    for (uint32_t i = threadIdx.x; i < nb; i += kBinThreads) cur[i] = o[(int64_t)i * nwg];
+    __syncthreads();
+    const LevelP lp = plan_level(g, l);
+    const int col = plan.col[slot];
+    uint16_t* ii = item_idx + plan.item_off[slot];
+    float* iv = item_val + plan.item_off[slot] * F;
+    const int64_t p0 = (int64_t)blockIdx.x * kBinChunkPts;
+    const int64_t p1 = p0 + kBinChunkPts < M ? p0 + kBinChunkPts : M;
+    for (int64_t p = p0 + threadIdx.x; p < p1; p += kBinThreads) {
+        const PointIn q = fetch_point(src, p, false);
+        const Corners c = level_corners(lp, q.x, q.y, q.z);
+        float d[F];
+        const float* dp = dfeat + p * stride + col;
+        if (F == 2 && ((((uintptr_t)dp) & 7) == 0)) { const f32x2 t = *(const f32x2*)dp; d[0] = t.x; d[F - 1] = t.y; }
+        else {
+#pragma unroll
+            for (int f = 0; f < F; ++f) d[f] = dp[f];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t fl = c.idx[k] * (uint32_t)F;
+            const uint32_t pos = atomicAdd(&cur[fl / kPartFloats], 1u);
+            ii[pos] = (uint16_t)(fl % kPartFloats);
+            if (F == 2) { f32x2 t; t.x = c.w[k] * d[0]; t.y = c.w[k] * d[F - 1]; *(f32x2*)(iv + (int64_t)pos * 2) = t; }
+            else {
+#pragma unroll
+                for (int f = 0; f < F; ++f) iv[(int64_t)pos * F + f] = c.w[k] * d[f];
+            }
+        }
+    }
+}
+
+// pass 4: one workgroup per partition: sum the bin into LDS, then Adam over the partition with the gradient from LDS
+template <int F>
+__global__ __launch_bounds__(kUpdThreads) void table_update_kernel(GridDev g, BinPlan plan,
+                                                                   const uint32_t* __restrict__ bin_start,
+                                                                   const uint16_t* __restrict__ item_idx,
+                                                                   const float* __restrict__ item_val, float* __restrict__ p,
+                                                                   float* __restrict__ m, float* __restrict__ v, AdamK k) {
+    extern __shared__ __attribute__((aligned(16))) float acc[];
+    const uint32_t part = blockIdx.x;
+    int slot = 0;
+    while (slot + 1 < plan.count && part >= plan.part_base[slot + 1]) ++slot;
+    const uint32_t bin = part - plan.part_base[slot];
+    const int l = plan.level[slot];
+    const int64_t level_floats = (int64_t)g.entries[l] * F;
+    const int64_t f0 = (int64_t)bin * kPartFloats;
+    const int n_here = (int)(level_floats - f0 < kPartFloats ? level_floats - f0 : kPartFloats);
+    const int n4 = n_here >> 2;
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
+    f4* acc4 = (f4*)acc;
+    for (int i = threadIdx.x; i < kPartFloats / 4; i += kUpdThreads) acc4[i] = zero;
+    __syncthreads();
+    const uint32_t* bs = bin_start + plan.part_base[slot] + slot;
+    const int64_t i0 = plan.item_off[slot] + bs[bin], i1 = plan.item_off[slot] + bs[bin + 1];
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += kUpdThreads) {
+        const int li = item_idx[i];
+        if (F == 2) {
+            const f32x2 t = *(const f32x2*)(item_val + i * 2);
+            atomicAdd(acc + li, t.x);
+            atomicAdd(acc + li + 1, t.y);
+        } else {
+#pragma unroll
+            for (int f = 0; f < F; ++f) atomicAdd(acc + li + f, item_val[i * F + f]);
+        }
+    }
+    __syncthreads();
+    const int64_t base = (int64_t)g.offset[l] * F + f0;
+    f4* p4 = (f4*)(p + base);
+    f4* m4 = (f4*)(m + base);
+    f4* v4 = (f4*)(v + base);
+    for (int i = threadIdx.x; i < n4; i += kUpdThreads) {
+        f4 pa = __builtin_nontemporal_load(p4 + i), ma = __builtin_nontemporal_load(m4 + i);
+        f4 va = __builtin_nontemporal_load(v4 + i);
+        const f4 ga = acc4[i];
+        adam4(pa, ga, ma, va, k);
+        __builtin_nontemporal_store(pa, p4 + i);
+        __builtin_nontemporal_store(ma, m4 + i);
+        __builtin_nontemporal_store(va, v4 + i);
+    }
+}
+
+int make_plan(const char* fn, const NerfGridCfg* grid, const NerfLevelSet* levels, int64_t n_points, int by_level,
+              BinPlan* plan, BinLayout* lay) {
+    if (!grid || !levels || levels->count < 1 || levels->count > grid->n_levels || levels->count > NERF_MAX_LEVELS) {
+        nerf_set_error("%s: bad level set", fn); return NERF_EINVAL;
+    }
+    if (n_points < 1 || n_points >= (1ll << 28)) { nerf_set_error("%s: n_points must be in [1, 2^28)", fn); return NERF_EINVAL; }
+    const int F = grid->n_features;
+    if (F != 1 && F != 2 && F != 4) { nerf_set_error("%s: unsupported: n_features_per_level must be 1, 2 or 4", fn); return NERF_EUNSUPPORTED; }
+    if (grid->total_entries >= (1ull << 32)) { nerf_set_error("%s: bad grid", fn); return NERF_EINVAL; }
+    const int nwg = (int)ceil_div64(n_points, kBinChunkPts);
+    *plan = BinPlan();
+    plan->count = levels->count;
+    int64_t hist = 0, items = 0;
+    uint32_t parts = 0;
+    for (int i = 0; i < levels->count; ++i) {
+        const int l = levels->level[i];
+        if (l < 0 || l >= grid->n_levels) { nerf_set_error("%s: level out of range", fn); return NERF_EINVAL; }
+        for (int j = 0; j < i; ++j)
+            if (levels->level[j] == l) { nerf_set_error("%s: level listed twice", fn); return NERF_EINVAL; }
+        const int64_t floats = (int64_t)grid->entries[l] * F;
+        const int64_t nb = ceil_div64(floats, kPartFloats);
+        if ((floats & 3) || (((int64_t)grid->offset[l] * F) & 3) || nb > kMaxBinsPerLevel || (uint64_t)grid->entries[l] * F >= (1ull << 32)) {
+            nerf_set_error("%s: unsupported: level %d (needs a multiple of 4 floats at a 16-byte offset and at most %d "
+                           "partitions of %d floats)", fn, l, kMaxBinsPerLevel, kPartFloats);
+            return NERF_EUNSUPPORTED;
+        }
+        plan->level[i] = l;
+        plan->col[i] = (by_level ? l : i) * F;
+        plan->nbins[i] = (uint32_t)nb;
+        plan->part_base[i] = parts;
+        plan->hist_off[i] = hist;
+        plan->item_off[i] = items;
+        parts += (uint32_t)nb;
+        hist += nb * nwg;
+        items += 8 * n_points;
+    }
+    plan->part_base[levels->count] = parts;
+    auto up = [](int64_t b) { return (b + 255) & ~(int64_t)255; };
+    lay->nwg = nwg;
+    lay->hist = 0;
+    lay->bin_start = up(hist * 4);
+    lay->item_idx = lay->bin_start + up(((int64_t)parts + levels->count) * 4);
+    lay->item_val = lay->item_idx + up(items * 2);
+    lay->total = lay->item_val + up(items * F * 4);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int64_t nerf_table_bin_workspace_bytes(const NerfGridCfg* grid, const NerfLevelSet* levels, int64_t n_points) {
+    BinPlan plan;
+    BinLayout lay;
+    const int rc = make_plan("nerf_table_bin_workspace_bytes", grid, levels, n_points, 0, &plan, &lay);
+    return rc ? (int64_t)(rc < 0 ? rc : -rc) : lay.total;
+}
+
+extern "C" int nerf_table_bin_levels(const NerfGridCfg* grid, const NerfPointSrc* src, const NerfLevelSet* levels,
+                                     const float* dfeat, int64_t dfeat_stride, int dfeat_by_level, void* workspace,
+                                     int64_t workspace_bytes, void* stream) {
+    NERF_REQUIRE(grid && dfeat && workspace, "null pointer");
+    int rc = nerf_check_src("nerf_table_bin_levels", src, false);
+    if (rc) return rc;
+    BinPlan plan;
+    BinLayout lay;
+    rc = make_plan("nerf_table_bin_levels", grid, levels, src->n_points, dfeat_by_level, &plan, &lay);
+    if (rc) return rc;
+    NERF_REQUIRE(workspace_bytes >= lay.total && (((uintptr_t)workspace) & 15) == 0, "workspace too small or not 16-byte aligned");
+    const int F = grid->n_features;
+    for (int i = 0; i < plan.count; ++i)
+        NERF_REQUIRE(dfeat_stride >= plan.col[i] + F, "dfeat_stride smaller than the last gradient column");
+    const GridDev g = make_grid_dev(grid);
+    char* ws = (char*)workspace;
+    uint32_t* hist = (uint32_t*)(ws + lay.hist);
+    uint32_t* bin_start = (uint32_t*)(ws + lay.bin_start);
+    uint16_t* item_idx = (uint16_t*)(ws + lay.item_idx);
+    float* item_val = (float*)(ws + lay.item_val);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 nb((unsigned)lay.nwg, (unsigned)plan.count);
+    const int64_t M = src->n_points;
+#define BIN_PASSES(FF)                                                                                                 \
+    do {                                                                                                               \
+        bin_count_kernel<FF><<<nb, kBinThreads, 0, st>>>(g, *src, plan, M, lay.nwg, hist);                             \
+        bin_scan_kernel<<<(unsigned)plan.count, kBinThreads, 0, st>>>(plan, lay.nwg, hist, bin_start);                 \
+        bin_fill_kernel<FF><<<nb, kBinThreads, 0, st>>>(g, *src, plan, M, lay.nwg, hist, dfeat, dfeat_stride, item_idx,  \
+                                                        item_val);                                                     \
+    } while (0)
+    switch (F) {
+        case 1: BIN_PASSES(1); break;
+        case 2: BIN_PASSES(2); break;
+        default: BIN_PASSES(4); break;
+    }
+#undef BIN_PASSES
+    return nerf_launch_status("nerf_table_bin_levels");
+}
+
+extern "C" int nerf_table_update_binned(const NerfGridCfg* grid, const NerfLevelSet* levels, int64_t n_points,
+                                        const void* workspace, int64_t workspace_bytes, float* table, float* exp_avg,
+                                        float* exp_avg_sq, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                        int64_t step, float grad_scale, void* stream) {
+    NERF_REQUIRE(grid && workspace && table && exp_avg && exp_avg_sq, "null pointer");
+    NERF_REQUIRE(step >= 1, "bad step");
+    NERF_REQUIRE((((uintptr_t)table | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq | (uintptr_t)workspace) & 15) == 0,
+                 "buffers must be 16-byte aligned");
+    BinPlan plan;
+    BinLayout lay;
+    const int rc = make_plan("nerf_table_update_binned", grid, levels, n_points, 0, &plan, &lay);
+    if (rc) return rc;
+    NERF_REQUIRE(workspace_bytes >= lay.total, "workspace too small");
+    const GridDev g = make_grid_dev(grid);
+    const char* ws = (const char*)workspace;
+    const uint32_t* bin_start = (const uint32_t*)(ws + lay.bin_start);
+    const uint16_t* item_idx = (const uint16_t*)(ws + lay.item_idx);
+    const float* item_val = (const float*)(ws + lay.item_val);
+    const AdamK k = make_adam_k(lr, beta1, beta2, eps, weight_decay, step, grad_scale);
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned nb = plan.part_base[plan.count];
+    const int lds_bytes = kPartFloats * (int)sizeof(float);
+#define UPDATE(FF)                                                                                                     \
+    do {                                                                                                               \
+        auto kern = table_update_kernel<FF>;                                                                           \
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);  \
+        if (e != hipSuccess) { nerf_set_error("nerf_table_update_binned: LDS attribute: %s", hipGetErrorString(e)); return (int)e; } \
+        kern<<<nb, kUpdThreads, lds_bytes, st>>>(g, plan, bin_start, item_idx, item_val, table, exp_avg, exp_avg_sq, k); \
+    } while (0)
+    switch (grid->n_features) {
+        case 1: UPDATE(1); break;
+        case 2: UPDATE(2); break;
+        default: UPDATE(4); break;
+    }
+#undef UPDATE
+    return nerf_launch_status("nerf_table_update_binned");
+}
