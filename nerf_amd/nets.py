@@ -208,7 +208,25 @@ class _FieldFn(torch.autograd.Function):
         unit = src.n_samples if src.mode == 1 else 1            # points per ray (chunks are cut between rays)
         rows = src.n_points // unit
         cut = int(rows * pipe.early_fraction) if pipe is not None else 0
-        if pipe is None or not direct or cut * unit < 65536 or (rows - cut) * unit < 65536:
+        if pipe is not None and direct and pipe.binned_levels:
+            # binned table update: one backward launch; the corner updates of the large levels are sorted into table
+            # partitions on this stream (FusedAdam.step sums and applies them in one pass), the small dense levels
+            # scatter on their own stream beside it
+            check(lib().nerf_field_bwd(C.byref(net.encoder.cfg), C.byref(net.net_cfg), ptr(table), ptr(sigma_w), ptr(color_w),
+                                       ptr(latent), net.N, C.byref(src), ptr(xh), ptr(dsigma), ptr(drgb),
+                                       ptr(dfeat), None, ptr(dsw), ptr(dcw), ptr(dlat), stream()), 'nerf_field_bwd')
+            pipe.begin(dtable)
+            pipe.keep = [dfeat, dsigma, drgb, xh, ctx.src_kwargs]
+            if pipe.groups:
+                if pipe.scatter_stream is None:
+                    pipe.scatter_stream = torch.cuda.Stream()
+                done = torch.cuda.Event()
+                done.record()
+                with torch.cuda.stream(pipe.scatter_stream):
+                    pipe.scatter_stream.wait_event(done)
+                    net.scatter_levels_pipelined(src, dfeat, dtable, final=True)
+            pipe.bin(net.encoder.cfg, src, dfeat, dfeat.shape[1], True, dtable)
+        elif pipe is None or not direct or cut * unit < 65536 or (rows - cut) * unit < 65536:
             check(lib().nerf_field_bwd(C.byref(net.encoder.cfg), C.byref(net.net_cfg), ptr(table), ptr(sigma_w), ptr(color_w),
                                        ptr(latent), net.N, C.byref(src), ptr(xh), ptr(dsigma), ptr(drgb),
                                        ptr(dfeat), None, ptr(dsw), ptr(dcw), ptr(dlat), stream()), 'nerf_field_bwd')
@@ -387,12 +405,13 @@ class NeRFNetwork(nn.Module):
         under data parallelism, the gradient all-reduce) of a level can start while later levels still scatter."""
         cfg = self.encoder.cfg
         pipe = self.table_pipeline
-        if pipe is None:
+        if pipe is None or not self.direct_grads:       # (the pipeline works on param.grad itself)
             check(lib().nerf_hashgrid_scatter(C.byref(cfg), C.byref(src), ptr(dfeat), ptr(dtable), 0, cfg.n_levels, stream()),
                   'nerf_hashgrid_scatter')
             return
         pipe.begin(dtable)
         self.scatter_levels_pipelined(src, dfeat, dtable, final=True)
+        pipe.bin(cfg, src, dfeat, dfeat.shape[1], True, dtable)
 
     def scatter_levels_pipelined(self, src, dfeat, dtable, final):
         """One pass over the pipeline's level groups on the current stream; `final` marks the last part of the

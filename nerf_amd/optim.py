@@ -18,10 +18,27 @@ class TablePipeline(object):
     overlap almost perfectly; without the pipeline they run back to back.  Level groups are ordered with the
     large hashed levels first so that the tail left after the last scatter is a small dense level."""
 
-    def __init__(self, grid_cfg, n_features, levels=None, reduce=True):
+    def __init__(self, grid_cfg, n_features, levels=None, reduce=True, binned=None):
         """`levels`: restrict to these levels (the ones this rank owns under a level-sharded table, whose
-        gradient is complete without any all-reduce: pass reduce=False)."""
+        gradient is complete without any all-reduce: pass reduce=False).
+        `binned` (default: on whenever no table gradient has to be all-reduced, NERF_TABLE_BINNED=0 turns it off):
+        the levels larger than the LDS-privatised scatter takes go through the binned update (csrc/table_update.hip:
+        scatter and Adam in one pass, no gradient array); only the small dense levels keep scatter -> Adam."""
         L = grid_cfg.n_levels
+        need_reduce = reduce and dist.is_initialized() and dist.get_world_size() > 1
+        if binned is None:
+            binned = not need_reduce and os.environ.get('NERF_TABLE_BINNED', '1') != '0'
+        self.binned_levels = []
+        if binned:
+            own = list(range(L)) if levels is None else sorted(levels)
+            self.binned_levels = [l for l in own if int(grid_cfg.entries[l]) * n_features > 16 * 32768]
+            rest = [l for l in own if l not in self.binned_levels]
+            if levels is not None:
+                levels = rest
+        self.binned_set = None          # NerfLevelSet of binned_levels (made on first use)
+        self.binned_ws = None           # workspace of nerf_table_bin_levels, reused while large enough
+        self.binned_pending = None      # (n_points, workspace bytes) between backward and step
+        self.binned_fallback = False    # a second backward arrived before step(): gradients went to p.grad instead
         if levels is None:
             hashed = [(l, 1) for l in range(L) if grid_cfg.hashed[l]]
             dense = [l for l in range(L) if not grid_cfg.hashed[l]]
@@ -34,6 +51,7 @@ class TablePipeline(object):
             # hashed levels first (most Adam work released per scatter), small levels last: measured best of the
             # four obvious orders
             groups = hashed + big + small
+            groups = [(l0, cnt) for (l0, cnt) in groups if l0 not in self.binned_levels]
         else:       # owned levels are not contiguous: one group each, big hashed levels first
             groups = [(l, 1) for l in sorted(levels, key=lambda l: (-int(grid_cfg.entries[l]), l))]
         self.groups = groups
@@ -59,6 +77,56 @@ class TablePipeline(object):
         self.works = {}
         self.early_events = {}
         self.keep = []
+
+    # ---- binned levels ---------------------------------------------------------------------------------
+    def bin(self, cfg, src, dfeat, stride, by_level, dtable):
+        """Sort the corner updates of this backward pass into table partitions (no optimizer hyper-parameters needed
+        yet; FusedAdam.step applies them with nerf_table_update_binned).  One backward per step is the fast path: a
+        second backward before step() -- gradient accumulation -- falls back to the atomic scatter into p.grad."""
+        if not self.binned_levels:
+            return
+        import ctypes as C
+        from ._lib import NerfLevelSet
+        if self.binned_set is None:
+            ls = NerfLevelSet()
+            ls.count = len(self.binned_levels)
+            for i, l in enumerate(self.binned_levels):
+                ls.level[i] = l
+            self.binned_set = ls
+        if self.binned_pending is not None or self.binned_fallback:
+            if self.binned_pending is not None:         # move the earlier pass's updates into the gradient
+                src0, dfeat0, stride0, by0 = self.binned_keep
+                self._scatter_classic(cfg, src0, dfeat0, stride0, by0, dtable)
+                self.binned_pending = None
+            self.binned_fallback = True
+            self._scatter_classic(cfg, src, dfeat, stride, by_level, dtable)
+            return
+        nbytes = lib().nerf_table_bin_workspace_bytes(C.byref(cfg), C.byref(self.binned_set), src.n_points)
+        if nbytes < 0:
+            check(int(nbytes), 'nerf_table_bin_workspace_bytes')
+        if self.binned_ws is None or self.binned_ws.numel() < nbytes:
+            self.binned_ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dfeat.device)
+        check(lib().nerf_table_bin_levels(C.byref(cfg), C.byref(src), C.byref(self.binned_set), ptr(dfeat), stride,
+                                          1 if by_level else 0, ptr(self.binned_ws), self.binned_ws.numel(), stream()),
+              'nerf_table_bin_levels')
+        self.binned_pending = (src.n_points, self.binned_ws.numel())
+        self.binned_keep = (src, dfeat, stride, by_level)
+
+    def _scatter_classic(self, cfg, src, dfeat, stride, by_level, dtable):
+        import ctypes as C
+        F = cfg.n_features
+        if by_level:
+            for l in self.binned_levels:
+                check(lib().nerf_hashgrid_scatter(C.byref(cfg), C.byref(src), ptr(dfeat), ptr(dtable), l, 1, stream()),
+                      'nerf_hashgrid_scatter')
+        else:
+            check(lib().nerf_hashgrid_scatter_levels(C.byref(cfg), C.byref(src), C.byref(self.binned_set), ptr(dfeat), stride,
+                                                     ptr(dtable), stream()), 'nerf_hashgrid_scatter_levels')
+
+    def drop_binned(self):
+        self.binned_pending = None
+        self.binned_keep = None
+        self.binned_fallback = False
 
     def level_partial(self, l0):
         """A first part of the level group's scatter has been issued on the CURRENT stream (atomics commute, so
@@ -117,6 +185,8 @@ class FusedAdam(torch.optim.Optimizer):
         if self._grads_cleared:       # the last step() already cleared them in its own pass
             self._grads_cleared = False
             return
+        if self._pipeline is not None:
+            self._pipeline.drop_binned()      # binned corner updates of a backward that is being discarded
         for group in self.param_groups:
             for p in group['params']:
                 if p.grad is not None:
@@ -134,8 +204,14 @@ class FusedAdam(torch.optim.Optimizer):
                     st['step'] = 0
                     st['exp_avg'] = torch.zeros_like(p)
                     st['exp_avg_sq'] = torch.zeros_like(p)
+                    # The moments are first used on the pipeline's side stream, which only waits for backward events
+                    # recorded BEFORE these fills were issued: without this one-time wait the fills can land after the
+                    # first Adam pass and wipe its moments (v = 0 with m != 0 then divides by eps on the next step).
+                    torch.cuda.current_stream().synchronize()
                 st['step'] += 1
                 pipe = self._pipeline
+                if p is self._table_param and pipe is not None and pipe.binned_levels:
+                    self._binned_table_step(p, st, group, b1, b2, pipe)
                 if p is self._table_param and self._sharding is not None:
                     # level-sharded table: only the owned levels have (complete) gradients and moments here
                     self._sharding.dirty = True
@@ -144,6 +220,14 @@ class FusedAdam(torch.optim.Optimizer):
                     continue
                 if pipe is not None and p is self._table_param and pipe.pending:
                     self._pipelined_table_step(p, st, group, b1, b2, pipe)
+                    continue
+                if pipe is not None and p is self._table_param and pipe.binned_levels:
+                    # no backward reached the table this step: the remaining (small) levels still take their Adam step
+                    flat_p, flat_g = p.view(-1), p.grad.view(-1)
+                    flat_m, flat_v = st['exp_avg'].view(-1), st['exp_avg_sq'].view(-1)
+                    for (l0, cnt) in pipe.groups:
+                        a, b = pipe.slices[l0]
+                        self._adam(flat_p[a:b], flat_g[a:b], flat_m[a:b], flat_v[a:b], group, b1, b2, st['step'])
                     continue
                 self._adam(p, p.grad, st['exp_avg'], st['exp_avg_sq'], group, b1, b2, st['step'])
         self._grads_cleared = True
@@ -167,6 +251,29 @@ class FusedAdam(torch.optim.Optimizer):
         if self._sharding is not None:
             return True     # level-sharded: every owner already holds the complete gradient of its levels
         return self._pipeline is not None and self._pipeline.pending and bool(self._pipeline.works)
+
+    def _binned_table_step(self, p, st, group, b1, b2, pipe):
+        """The levels that go through the binned update: one pass that sums the step's corner updates per table
+        partition in LDS and applies Adam (main stream; the small levels' scatter -> Adam runs beside it)."""
+        import ctypes as C
+        cfg = self._model.encoder.cfg
+        if pipe.binned_pending is not None:
+            n_points, nbytes = pipe.binned_pending
+            check(lib().nerf_table_update_binned(C.byref(cfg), C.byref(pipe.binned_set), n_points, ptr(pipe.binned_ws), nbytes,
+                                                 ptr(p), ptr(st['exp_avg']), ptr(st['exp_avg_sq']), group['lr'], b1, b2,
+                                                 group['eps'], group['weight_decay'], st['step'], self.grad_scale, stream()),
+                  'nerf_table_update_binned')
+        else:
+            # gradient accumulation (several backward passes) or no backward at all: the gradients of these levels
+            # are in p.grad (possibly all zero) -- the plain streaming Adam pass, level by level
+            flat_p, flat_g = p.view(-1), p.grad.view(-1)
+            flat_m, flat_v = st['exp_avg'].view(-1), st['exp_avg_sq'].view(-1)
+            F = cfg.n_features
+            for l in pipe.binned_levels:
+                a = int(cfg.offset[l]) * F
+                b = a + int(cfg.entries[l]) * F
+                self._adam(flat_p[a:b], flat_g[a:b], flat_m[a:b], flat_v[a:b], group, b1, b2, st['step'])
+        pipe.drop_binned()
 
     def _pipelined_table_step(self, p, st, group, b1, b2, pipe):
         main = torch.cuda.current_stream()

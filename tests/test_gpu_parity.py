@@ -250,14 +250,17 @@ def test_adam_vs_torch():
         torch.testing.assert_close(pg.detach().cpu(), pc.detach(), rtol=1e-5, atol=1e-6)
 
 
-def test_train_steps_vs_oracle():
+@pytest.mark.parametrize('name,binned', [('small', '1'), ('base19', '1'), ('base19', '0')])
+def test_train_steps_vs_oracle(name, binned, monkeypatch):
     """A short training trace (loss per step) of the HIP path against the CPU oracle:
-    same rays, same noise, same init, Adam groups of train.py:84-88."""
+    same rays, same noise, same init, Adam groups of train.py:84-88.  'base19' has levels large enough for the
+    binned table update (csrc/table_update.hip); binned='0' forces the scatter -> Adam pipeline on the same levels."""
     from nerf_amd.optim import FusedAdam
     from nerf_amd.renderer import NerfRenderer
     from nerf_amd import helpers
     from oracle import ref_cpu
-    net, ora = _make_pair(NET_CFGS['small'])
+    monkeypatch.setenv('NERF_TABLE_BINNED', binned)
+    net, ora = _make_pair(NET_CFGS[name])
     with torch.no_grad():
         ora.latent_emb.zero_()
         net.latent_emb.zero_()
@@ -268,6 +271,7 @@ def test_train_steps_vs_oracle():
                     {'params': [net.latent_emb], 'lr': 2e-2},
                     {'params': list(net.sigma_net.parameters()) + list(net.color_net.parameters()), 'weight_decay': 1e-6, 'lr': 1e-3}],
                    betas=(0.9, 0.99), eps=1e-15).attach(net)
+    assert bool(net.table_pipeline.binned_levels) == (name == 'base19' and binned == '1')
     lo, lg = [], []
     for it in range(4):
         n, h, w, K, E, bg, noise, gt = _batch(10 + it, 96)
@@ -286,7 +290,21 @@ def test_train_steps_vs_oracle():
         lg.append(float(loss_g))
     for a, b in zip(lg, lo):
         assert abs(a - b) <= 2e-4 * max(1.0, abs(b)), (lg, lo)
-    torch.testing.assert_close(net.sigma_net.params.detach().cpu(), ora.sigma_params.detach(), rtol=0, atol=2e-3)
+    # (lr 1e-3 x 4 steps: a weight whose tiny gradient flips sign with the summation order moves by up to 2 lr per step)
+    torch.testing.assert_close(net.sigma_net.params.detach().cpu(), ora.sigma_params.detach(), rtol=0,
+                               atol=2e-3 if name == 'small' else 3e-3)
+    # Adam invariants of the table: a parameter that ever saw a gradient has both moments, and the moments agree with
+    # the oracle's (torch.optim.Adam) wherever they are not summation noise.  (The first pipelined step once lost its
+    # moments to a late zero-fill: v = 0 under m != 0 divides by eps on the next step.)
+    st = og.state[net.encoder.params]
+    m, v = st['exp_avg'].cpu(), st['exp_avg_sq'].cpu()
+    assert int(((m != 0) & (v == 0)).sum()) == 0
+    so = oo.state[ora.encoder_params]
+    # (4 steps of Adam with eps = 1e-15 turn summation noise on near-zero gradients into +-lr parameter steps and the
+    # fine samples then fall into other cells of the fine levels: entries are not comparable one by one, totals are)
+    mo, vo = so['exp_avg'], so['exp_avg_sq']
+    assert abs(float(m.abs().sum()) / float(mo.abs().sum()) - 1) < 5e-2
+    assert abs(float(v.sum()) / float(vo.sum()) - 1) < 5e-2
 
 
 def test_inferencer_chunking_and_thresh_depth():
