@@ -302,6 +302,18 @@ def main():
             lv = int(cls[1:].split(' ')[0])             # levels per launch
             per_level = n_pts_scatter * (2 * 8 * 2 * 4 + 2 * 4)     # RMW of 8 corners x F floats + F floats of dfeat
             bytes_step = per_level * lv * (launches / args.profile_steps) / n_chunks
+        elif base in ('nerf_table_update_binned', 'nerf_table_bin_levels') and pipe is not None and pipe.binned_levels:
+            # binned table update (csrc/table_update.hip): an item = one corner update = 2 B index + 4F B values;
+            # the update pass moves 24 B per parameter (p, m, v read and written) and reads every item once; the bin
+            # passes read d(features) once per level and write every item once
+            cfg_ = model.encoder.cfg
+            F_ = cfg_.n_features
+            n_items = 8 * n_pts_scatter * len(pipe.binned_levels)
+            n_binned_params = sum(int(cfg_.entries[l]) * F_ for l in pipe.binned_levels)
+            if base == 'nerf_table_update_binned':
+                bytes_step = 24 * n_binned_params + n_items * (2 + 4 * F_)
+            else:
+                bytes_step = n_items * (2 + 4 * F_) + n_pts_scatter * len(pipe.binned_levels) * 4 * F_
         elif base == 'nerf_hashgrid_encode_levels':
             bytes_step = algorithmic_bytes(base, args.rays, n_params, Sc=sum(STEPS))   # both launches of one step together
         else:
@@ -329,7 +341,15 @@ def main():
                 'avg_launch_ms': k['avg_launch_ms'], 'launches_per_step': k['launches_per_step'],
                 'algorithmic_bytes_per_launch': k.get('algorithmic_bytes_per_launch')}
     with_bytes = [k for k in kernels if k.get('algorithmic_GBps')]
+    if pipe is not None and pipe.binned_levels and model_sharded is None:
+        # binned table update: the LDS-privatised scatter of the small dense levels runs on its own stream BESIDE the
+        # bin and update passes (its wall time is stretched by sharing the CUs and is not on the critical path), so
+        # the dominant kernel is picked among the launches of the main stream
+        with_bytes = [k for k in with_bytes if not k['name'].startswith('nerf_hashgrid_scatter')]
     roofline = roofline_of(with_bytes[0]) if with_bytes else None
+    if roofline and roofline['kernel'] == 'nerf_table_update_binned':
+        roofline['note'] = ('scatter + Adam of the hashed and large dense levels in one pass: every bin of corner updates is '
+                            'summed in LDS, then p, m, v stream through the Adam update (24 B per parameter)')
     if roofline and roofline['kernel'].startswith('nerf_hashgrid_scatter'):
         roofline['note'] = ('random 8-byte atomic adds: bounded by the memory-side atomic rate (one 64-B request per table '
                             'entry), not by bytes; the launches overlap the Adam pass of the previous level')

@@ -237,10 +237,12 @@ int nerf_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
  * and the large dense levels -- a level smaller than one partition works but serialises on one workgroup.
  * The caller owns the workspace; it must stay untouched between the two calls. */
 int64_t nerf_table_bin_workspace_bytes(const NerfGridCfg* grid, const NerfLevelSet* levels, int64_t n_points); /* < 0: error */
-/* dfeat_by_level == 0: the F gradient columns of levels->level[i] start at column i*F of dfeat (as in
- * nerf_hashgrid_scatter_levels); != 0: at column level*F (the full [M, L*F] matrix nerf_field_bwd writes). */
+/* dfeat_cols (host array of levels->count ints, nullable): first of the F gradient columns of levels->level[i] in a
+ * row of dfeat; NULL = i*F (as in nerf_hashgrid_scatter_levels).  The full [M, L*F] matrix nerf_field_bwd writes
+ * has level l at column l*F. */
 int nerf_table_bin_levels(const NerfGridCfg* grid, const NerfPointSrc* src, const NerfLevelSet* levels, const float* dfeat,
-                          int64_t dfeat_stride, int dfeat_by_level, void* workspace, int64_t workspace_bytes, void* stream);
+                          int64_t dfeat_stride, const int32_t* dfeat_cols, void* workspace, int64_t workspace_bytes,
+                          void* stream);
 /* table / exp_avg / exp_avg_sq: the WHOLE table's tensors (level offsets come from grid); only the listed levels change.
  * n_points and levels must be those of the nerf_table_bin_levels call that filled the workspace. */
 int nerf_table_update_binned(const NerfGridCfg* grid, const NerfLevelSet* levels, int64_t n_points, const void* workspace,

@@ -34,7 +34,7 @@ struct BinPlan {
     int col[NERF_MAX_LEVELS];                    // first d(features) column of the level
     uint32_t nbins[NERF_MAX_LEVELS];
     uint32_t part_base[NERF_MAX_LEVELS + 1];     // running sum of nbins: workgroup id of the update kernel -> level slot
-    int64_t hist_off[NERF_MAX_LEVELS];           // in uint32 units: the slot's [bin][workgroup] histogram / offsets
+    int64_t hist_off[NERF_MAX_LEVELS];           // in uint32 units: the slot's [workgroup][bin] histogram / offsets
     int64_t item_off[NERF_MAX_LEVELS];           // in items: the slot's 8 * n_points items
 };
 
@@ -76,51 +76,51 @@ __global__ __launch_bounds__(kBinThreads) void bin_count_kernel(GridDev g, NerfP
         for (int k = 0; k < 8; ++k) atomicAdd(&lh[(c.idx[k] * (uint32_t)F) / kPartFloats], 1u);
     }
     __syncthreads();
-    uint32_t* dst = hist + plan.hist_off[slot] + blockIdx.x;
-    for (uint32_t i = threadIdx.x; i < nb; i += kBinThreads) dst[(int64_t)i * nwg] = lh[i];
+    uint32_t* dst = hist + plan.hist_off[slot] + (int64_t)blockIdx.x * nb;      // [workgroup][bin]: coalesced
+    for (uint32_t i = threadIdx.x; i < nb; i += kBinThreads) dst[i] = lh[i];
 }
 
-// pass 2: turn a slot's [bin][workgroup] counts (in place) into where every workgroup writes its items of every
-// bin; bin_start[b] = first item of bin b, bin_start[nbins] = 8 * n_points.  One workgroup per slot, a thread per
-// bin (the nwg counts of a bin are contiguous), block scan of the bin totals in LDS.
+// pass 2: turn a slot's [workgroup][bin] counts (in place) into where every workgroup writes its items of every bin:
+// offset(bin, wg) = items of all earlier bins + items of this bin from earlier workgroups.  bin_start[b] = first item
+// of bin b, bin_start[nbins] = 8 * n_points.  One workgroup per slot; thread t takes bins t, t + 1024, ... so that
+// every pass over the workgroups is a coalesced row read.
 __global__ __launch_bounds__(kBinThreads) void bin_scan_kernel(BinPlan plan, int nwg, uint32_t* __restrict__ hist,
                                                                uint32_t* __restrict__ bin_start) {
     __shared__ uint32_t part[kBinThreads];
-    constexpr int kPer = kMaxBinsPerLevel / kBinThreads;        // bins per thread (consecutive)
+    __shared__ uint32_t carry_s;
     const int slot = blockIdx.x;
     const uint32_t nb = plan.nbins[slot];
     uint32_t* h = hist + plan.hist_off[slot];
     uint32_t* bs = bin_start + plan.part_base[slot] + slot;
-    uint32_t tot[kPer];
-    uint32_t sum = 0;
-#pragma unroll
-    for (int j = 0; j < kPer; ++j) {
-        const uint32_t b = threadIdx.x * kPer + j;
-        uint32_t t = 0;
-        if (b < nb) for (int w = 0; w < nwg; ++w) t += h[(int64_t)b * nwg + w];
-        tot[j] = t;
-        sum += t;
-    }
-    part[threadIdx.x] = sum;
+    if (threadIdx.x == 0) carry_s = 0u;
     __syncthreads();
-    for (int off = 1; off < kBinThreads; off <<= 1) {      // Hillis-Steele inclusive scan of the per-thread sums
-        const uint32_t add = threadIdx.x >= (unsigned)off ? part[threadIdx.x - off] : 0u;
+    for (uint32_t b0 = 0; b0 < nb; b0 += kBinThreads) {
+        const uint32_t b = b0 + threadIdx.x;
+        uint32_t tot = 0;
+        if (b < nb) for (int w = 0; w < nwg; ++w) tot += h[(int64_t)w * nb + b];
+        part[threadIdx.x] = tot;
         __syncthreads();
-        part[threadIdx.x] += add;
-        __syncthreads();
-    }
-    uint32_t run = part[threadIdx.x] - sum;
-#pragma unroll
-    for (int j = 0; j < kPer; ++j) {
-        const uint32_t b = threadIdx.x * kPer + j;
+        for (int off = 1; off < kBinThreads; off <<= 1) {      // Hillis-Steele inclusive scan of this round's bin totals
+            const uint32_t add = threadIdx.x >= (unsigned)off ? part[threadIdx.x - off] : 0u;
+            __syncthreads();
+            part[threadIdx.x] += add;
+            __syncthreads();
+        }
+        const uint32_t carry = carry_s;
+        uint32_t run = carry + part[threadIdx.x] - tot;         // first item of bin b
         if (b < nb) {
             bs[b] = run;
-            uint32_t r = run;
-            for (int w = 0; w < nwg; ++w) { const uint32_t c = h[(int64_t)b * nwg + w]; h[(int64_t)b * nwg + w] = r; r += c; }
+            for (int w = 0; w < nwg; ++w) {
+                const uint32_t c = h[(int64_t)w * nb + b];
+                h[(int64_t)w * nb + b] = run;
+                run += c;
+            }
         }
-        run += tot[j];
+        __syncthreads();
+        if (threadIdx.x == kBinThreads - 1) carry_s = carry + part[kBinThreads - 1];
+        __syncthreads();
     }
-    if (threadIdx.x == kBinThreads - 1) bs[nb] = part[kBinThreads - 1];
+    if (threadIdx.x == 0) bs[nb] = carry_s;
 }
 
 // pass 3: write every item (partition-local float offset, F gradient values) to its place in its bin
@@ -132,8 +132,8 @@ __global__ __launch_bounds__(kBinThreads) void bin_fill_kernel(GridDev g, NerfPo
     __shared__ uint32_t cur[kMaxBinsPerLevel];
     const int slot = blockIdx.y, l = plan.level[slot];
     const uint32_t nb = plan.nbins[slot];
-    const uint32_t* o = offs + plan.hist_off[slot] + blockIdx.x;
-    for (uint32_t i = threadIdx.x; i < nb; i += kBinThreads) cur[i] = o[(int64_t)i * nwg];
+    const uint32_t* o = offs + plan.hist_off[slot] + (int64_t)blockIdx.x * nb;
+    for (uint32_t i = threadIdx.x; i < nb; i += kBinThreads) cur[i] = o[i];
     __syncthreads();
     const LevelP lp = plan_level(g, l);
     const int col = plan.col[slot];
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(kUpdThreads) void table_update_kernel(GridDev g, Bi
     }
 }
 
-int make_plan(const char* fn, const NerfGridCfg* grid, const NerfLevelSet* levels, int64_t n_points, int by_level,
+int make_plan(const char* fn, const NerfGridCfg* grid, const NerfLevelSet* levels, int64_t n_points, const int32_t* cols,
               BinPlan* plan, BinLayout* lay) {
     if (!grid || !levels || levels->count < 1 || levels->count > grid->n_levels || levels->count > NERF_MAX_LEVELS) {
         nerf_set_error("%s: bad level set", fn); return NERF_EINVAL;
@@ -242,7 +242,8 @@ int make_plan(const char* fn, const NerfGridCfg* grid, const NerfLevelSet* level
             return NERF_EUNSUPPORTED;
         }
         plan->level[i] = l;
-        plan->col[i] = (by_level ? l : i) * F;
+        plan->col[i] = cols ? cols[i] : i * F;
+        if (plan->col[i] < 0) { nerf_set_error("%s: negative gradient column", fn); return NERF_EINVAL; }
         plan->nbins[i] = (uint32_t)nb;
         plan->part_base[i] = parts;
         plan->hist_off[i] = hist;
@@ -267,19 +268,19 @@ int make_plan(const char* fn, const NerfGridCfg* grid, const NerfLevelSet* level
 extern "C" int64_t nerf_table_bin_workspace_bytes(const NerfGridCfg* grid, const NerfLevelSet* levels, int64_t n_points) {
     BinPlan plan;
     BinLayout lay;
-    const int rc = make_plan("nerf_table_bin_workspace_bytes", grid, levels, n_points, 0, &plan, &lay);
+    const int rc = make_plan("nerf_table_bin_workspace_bytes", grid, levels, n_points, nullptr, &plan, &lay);
     return rc ? (int64_t)(rc < 0 ? rc : -rc) : lay.total;
 }
 
 extern "C" int nerf_table_bin_levels(const NerfGridCfg* grid, const NerfPointSrc* src, const NerfLevelSet* levels,
-                                     const float* dfeat, int64_t dfeat_stride, int dfeat_by_level, void* workspace,
+                                     const float* dfeat, int64_t dfeat_stride, const int32_t* dfeat_cols, void* workspace,
                                      int64_t workspace_bytes, void* stream) {
     NERF_REQUIRE(grid && dfeat && workspace, "null pointer");
     int rc = nerf_check_src("nerf_table_bin_levels", src, false);
     if (rc) return rc;
     BinPlan plan;
     BinLayout lay;
-    rc = make_plan("nerf_table_bin_levels", grid, levels, src->n_points, dfeat_by_level, &plan, &lay);
+    rc = make_plan("nerf_table_bin_levels", grid, levels, src->n_points, dfeat_cols, &plan, &lay);
     if (rc) return rc;
     NERF_REQUIRE(workspace_bytes >= lay.total && (((uintptr_t)workspace) & 15) == 0, "workspace too small or not 16-byte aligned");
     const int F = grid->n_features;
@@ -320,7 +321,7 @@ extern "C" int nerf_table_update_binned(const NerfGridCfg* grid, const NerfLevel
                  "buffers must be 16-byte aligned");
     BinPlan plan;
     BinLayout lay;
-    const int rc = make_plan("nerf_table_update_binned", grid, levels, n_points, 0, &plan, &lay);
+    const int rc = make_plan("nerf_table_update_binned", grid, levels, n_points, nullptr, &plan, &lay);
     if (rc) return rc;
     NERF_REQUIRE(workspace_bytes >= lay.total, "workspace too small");
     const GridDev g = make_grid_dev(grid);

@@ -265,7 +265,8 @@ class LevelSharding(object):
         """dtable[my levels] += scatter of d(features) from the points of all ranks.  The gradient rows of my own
         points are scattered while the all-to-all that brings the other ranks' rows is in flight; with a
         TablePipeline the remote part then goes level by level with an event after each (Adam follows on the side
-        stream)."""
+        stream).  Levels that take the binned update (TablePipeline.binned_levels) are not scattered at all: the
+        corner updates of all ranks' points are sorted into table partitions once the exchange has completed."""
         M, W, r, wm = dfeat.shape[0], self.world, self.rank, self.width[self.rank]
         send = self.split(dfeat)
         recv = torch.empty(W * M * wm, device=dfeat.device, dtype=torch.float32)
@@ -273,8 +274,20 @@ class LevelSharding(object):
         work = parallel.all_to_all_blocks(recv_blocks, send_blocks, async_op=True)
         if pipe is not None:
             pipe.begin(dtable)
-        if wm:
-            self._scatter(self._sub_src(src_all, r, r + 1, M), self.my_set, ptr(send_blocks[r]), wm, dtable)
+        binned = list(pipe.binned_levels) if pipe is not None else []
+        slot = {l: i for i, l in enumerate(self.mine)}
+        # the levels that keep the atomic scatter (all of mine without a pipeline, the small ones with the binned
+        # update): the rows of my own points go first, under the exchange
+        early = [l for l in self.mine if l not in binned]
+        if wm and early:
+            own = self._sub_src(src_all, r, r + 1, M)
+            if len(early) == len(self.mine):
+                self._scatter(own, self.my_set, ptr(send_blocks[r]), wm, dtable)
+            else:
+                for l in early:
+                    self._scatter(own, _level_set([l]), ptr(send_blocks[r]) + 4 * slot[l] * self.F, wm, dtable)
+        if wm and binned:
+            recv_blocks[r].copy_(send_blocks[r])        # recv becomes the whole [W*M, wm] gradient matrix, rank-major
         if work is not None:
             work.wait()
         if not wm:
@@ -284,13 +297,19 @@ class LevelSharding(object):
             for (a, b) in remote:
                 self._scatter(self._sub_src(src_all, a, b, M), self.my_set, ptr(recv_blocks[a]), wm, dtable)
             return
-        slot = {l: i for i, l in enumerate(self.mine)}
         for (l0, cnt) in pipe.groups:
             for l in range(l0, l0 + cnt):
                 one = _level_set([l])
                 for (a, b) in remote:
                     self._scatter(self._sub_src(src_all, a, b, M), one, ptr(recv_blocks[a]) + 4 * slot[l] * self.F, wm, dtable)
             pipe.level_done(l0, cnt)
+        if binned:
+            # binned update of the large levels: the corner updates of the points of ALL ranks are sorted into table
+            # partitions here; FusedAdam.step sums and applies them in one pass (no gradient array, no atomics)
+            from .nets import make_point_src
+            pipe.keep += [recv, src_all]
+            pipe.bin(self.cfg, make_point_src(**self._sub_src(src_all, 0, W, M)), recv, wm,
+                     {l: slot[l] * self.F for l in binned}, dtable)
 
     # ---- table consistency ---------------------------------------------------------------
     def level_slice(self, l):

@@ -43,6 +43,7 @@ class HashGridEncoding(nn.Module):
             raise ValueError(lib().nerf_last_error().decode())
         self.n_input_dims = 3
         self.n_output_dims = n_levels * n_features_per_level
+        self.level_cols = {l: l * n_features_per_level for l in range(n_levels)}    # columns of a level in a feature row
         g = None
         if seed is not None:
             g = torch.Generator(device='cpu').manual_seed(seed)
@@ -225,7 +226,7 @@ class _FieldFn(torch.autograd.Function):
                 with torch.cuda.stream(pipe.scatter_stream):
                     pipe.scatter_stream.wait_event(done)
                     net.scatter_levels_pipelined(src, dfeat, dtable, final=True)
-            pipe.bin(net.encoder.cfg, src, dfeat, dfeat.shape[1], True, dtable)
+            pipe.bin(net.encoder.cfg, src, dfeat, dfeat.shape[1], net.encoder.level_cols, dtable)
         elif pipe is None or not direct or cut * unit < 65536 or (rows - cut) * unit < 65536:
             check(lib().nerf_field_bwd(C.byref(net.encoder.cfg), C.byref(net.net_cfg), ptr(table), ptr(sigma_w), ptr(color_w),
                                        ptr(latent), net.N, C.byref(src), ptr(xh), ptr(dsigma), ptr(drgb),
@@ -411,7 +412,7 @@ class NeRFNetwork(nn.Module):
             return
         pipe.begin(dtable)
         self.scatter_levels_pipelined(src, dfeat, dtable, final=True)
-        pipe.bin(cfg, src, dfeat, dfeat.shape[1], True, dtable)
+        pipe.bin(cfg, src, dfeat, dfeat.shape[1], self.encoder.level_cols, dtable)
 
     def scatter_levels_pipelined(self, src, dfeat, dtable, final):
         """One pass over the pipeline's level groups on the current stream; `final` marks the last part of the

@@ -79,10 +79,11 @@ class TablePipeline(object):
         self.keep = []
 
     # ---- binned levels ---------------------------------------------------------------------------------
-    def bin(self, cfg, src, dfeat, stride, by_level, dtable):
+    def bin(self, cfg, src, dfeat, stride, cols, dtable):
         """Sort the corner updates of this backward pass into table partitions (no optimizer hyper-parameters needed
-        yet; FusedAdam.step applies them with nerf_table_update_binned).  One backward per step is the fast path: a
-        second backward before step() -- gradient accumulation -- falls back to the atomic scatter into p.grad."""
+        yet; FusedAdam.step applies them with nerf_table_update_binned).  `cols`: {level: first gradient column in a
+        row of dfeat}.  One backward per step is the fast path: a second backward before step() -- gradient
+        accumulation -- falls back to the atomic scatter into p.grad."""
         if not self.binned_levels:
             return
         import ctypes as C
@@ -95,33 +96,33 @@ class TablePipeline(object):
             self.binned_set = ls
         if self.binned_pending is not None or self.binned_fallback:
             if self.binned_pending is not None:         # move the earlier pass's updates into the gradient
-                src0, dfeat0, stride0, by0 = self.binned_keep
-                self._scatter_classic(cfg, src0, dfeat0, stride0, by0, dtable)
+                src0, dfeat0, stride0, cols0 = self.binned_keep
+                self._scatter_classic(cfg, src0, dfeat0, stride0, cols0, dtable)
                 self.binned_pending = None
             self.binned_fallback = True
-            self._scatter_classic(cfg, src, dfeat, stride, by_level, dtable)
+            self._scatter_classic(cfg, src, dfeat, stride, cols, dtable)
             return
         nbytes = lib().nerf_table_bin_workspace_bytes(C.byref(cfg), C.byref(self.binned_set), src.n_points)
         if nbytes < 0:
             check(int(nbytes), 'nerf_table_bin_workspace_bytes')
         if self.binned_ws is None or self.binned_ws.numel() < nbytes:
             self.binned_ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dfeat.device)
+        col_arr = (C.c_int32 * len(self.binned_levels))(*[int(cols[l]) for l in self.binned_levels])
         check(lib().nerf_table_bin_levels(C.byref(cfg), C.byref(src), C.byref(self.binned_set), ptr(dfeat), stride,
-                                          1 if by_level else 0, ptr(self.binned_ws), self.binned_ws.numel(), stream()),
+                                          col_arr, ptr(self.binned_ws), self.binned_ws.numel(), stream()),
               'nerf_table_bin_levels')
         self.binned_pending = (src.n_points, self.binned_ws.numel())
-        self.binned_keep = (src, dfeat, stride, by_level)
+        self.binned_keep = (src, dfeat, stride, cols)
 
-    def _scatter_classic(self, cfg, src, dfeat, stride, by_level, dtable):
+    def _scatter_classic(self, cfg, src, dfeat, stride, cols, dtable):
         import ctypes as C
-        F = cfg.n_features
-        if by_level:
-            for l in self.binned_levels:
-                check(lib().nerf_hashgrid_scatter(C.byref(cfg), C.byref(src), ptr(dfeat), ptr(dtable), l, 1, stream()),
-                      'nerf_hashgrid_scatter')
-        else:
-            check(lib().nerf_hashgrid_scatter_levels(C.byref(cfg), C.byref(src), C.byref(self.binned_set), ptr(dfeat), stride,
-                                                     ptr(dtable), stream()), 'nerf_hashgrid_scatter_levels')
+        from ._lib import NerfLevelSet
+        for l in self.binned_levels:        # one level at a time: its columns start at cols[l] of every row
+            one = NerfLevelSet()
+            one.count = 1
+            one.level[0] = l
+            check(lib().nerf_hashgrid_scatter_levels(C.byref(cfg), C.byref(src), C.byref(one), ptr(dfeat) + 4 * int(cols[l]),
+                                                     stride, ptr(dtable), stream()), 'nerf_hashgrid_scatter_levels')
 
     def drop_binned(self):
         self.binned_pending = None
@@ -173,8 +174,12 @@ class FusedAdam(torch.optim.Optimizer):
             sh = model.shard_levels(None if shard_levels is True else shard_levels)
             sh.force = True         # explicitly requested (or world > 1): also valid, if pointless, for one rank
             self._sharding = sh
+            # (the binned update stays off here by default: an owner sees the points of ALL ranks on a few levels, and
+            # the clustered points of a dense level then pile into a handful of partitions -- measured slower than the
+            # atomic scatter in tools/shard_step_emulate.py; NERF_TABLE_BINNED_SHARDED=1 turns it on)
             model.table_pipeline = TablePipeline(model.encoder.cfg, model.encoder.cfg.n_features, levels=sh.mine,
-                                                 reduce=False)
+                                                 reduce=False,
+                                                 binned=os.environ.get('NERF_TABLE_BINNED_SHARDED', '0') == '1')
             self._pipeline = model.table_pipeline
         elif pipeline:
             model.table_pipeline = TablePipeline(model.encoder.cfg, model.encoder.cfg.n_features)

@@ -57,7 +57,8 @@ def _run_binned(enc, src, levels, dfeat, stride, by_level, step, hyper):
     nbytes = lib().nerf_table_bin_workspace_bytes(C.byref(cfg), C.byref(ls), src.n_points)
     assert nbytes > 0
     ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
-    check(lib().nerf_table_bin_levels(C.byref(cfg), C.byref(src), C.byref(ls), ptr(dfeat), stride, int(by_level), ptr(ws),
+    cols = (C.c_int32 * len(levels))(*[l * cfg.n_features for l in levels]) if by_level else None
+    check(lib().nerf_table_bin_levels(C.byref(cfg), C.byref(src), C.byref(ls), ptr(dfeat), stride, cols, ptr(ws),
                                       nbytes, stream()), 'bin_levels')
     check(lib().nerf_table_update_binned(C.byref(cfg), C.byref(ls), src.n_points, ptr(ws), nbytes, ptr(p), ptr(m), ptr(v),
                                          *hyper[:5], step, hyper[5], stream()), 'update_binned')
@@ -115,8 +116,8 @@ def test_binned_update_rejects_bad_arguments():
     assert n > 0
     ws = torch.empty(n, dtype=torch.uint8, device='cuda')
     dfeat = torch.zeros(64, 4, device='cuda')
-    assert lib().nerf_table_bin_levels(C.byref(cfg), C.byref(src), C.byref(ls), ptr(dfeat), 4, 0, ptr(ws), n - 1, stream()) != 0
-    assert lib().nerf_table_bin_levels(C.byref(cfg), C.byref(src), C.byref(ls), ptr(dfeat), 3, 0, ptr(ws), n, stream()) != 0
+    assert lib().nerf_table_bin_levels(C.byref(cfg), C.byref(src), C.byref(ls), ptr(dfeat), 4, None, ptr(ws), n - 1, stream()) != 0
+    assert lib().nerf_table_bin_levels(C.byref(cfg), C.byref(src), C.byref(ls), ptr(dfeat), 3, None, ptr(ws), n, stream()) != 0
     p = enc.params.detach().clone()
     assert lib().nerf_table_update_binned(C.byref(cfg), C.byref(ls), 64, ptr(ws), n, ptr(p), ptr(p), None, 1e-2, 0.9, 0.99,
                                           1e-15, 0.0, 1, 1.0, stream()) != 0

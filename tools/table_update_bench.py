@@ -35,6 +35,7 @@ def main():
     ls.count = len(levels)
     for i, l in enumerate(levels):
         ls.level[i] = l
+    cols = (C.c_int32 * len(levels))(*[l * F for l in levels])
     p = enc.params.detach().clone()
     m, v, gr = torch.zeros_like(p), torch.zeros_like(p), torch.zeros_like(p)
     hyper = (1e-2, 0.9, 0.99, 1e-15, 0.0)
@@ -54,7 +55,7 @@ def main():
         return e0.elapsed_time(e1) / a.reps
 
     def bins():
-        check(lib().nerf_table_bin_levels(C.byref(cfg), C.byref(src), C.byref(ls), ptr(dfeat), 40, 1, ptr(ws), nbytes, stream()), 'bin')
+        check(lib().nerf_table_bin_levels(C.byref(cfg), C.byref(src), C.byref(ls), ptr(dfeat), 40, cols, ptr(ws), nbytes, stream()), 'bin')
 
     def upd():
         check(lib().nerf_table_update_binned(C.byref(cfg), C.byref(ls), M, ptr(ws), nbytes, ptr(p), ptr(m), ptr(v), *hyper, 1, 1.0,
