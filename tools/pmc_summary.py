@@ -26,6 +26,8 @@ ENTRY = [
     (r'scatter_(small_)?kernel', 'nerf_hashgrid_scatter'),
     (r'encode_levels_kernel', 'nerf_hashgrid_encode_levels'),
     (r'adam_kernel', 'nerf_adam_step'),
+    (r'table_update_kernel', 'nerf_table_update_binned'),
+    (r'bin_(count|scan|fill)_kernel', 'nerf_table_bin_levels'),
     (r'composite_fwd_kernel', 'nerf_composite_fwd'),
     (r'composite_bwd_kernel', 'nerf_composite_bwd'),
     (r'losses_kernel', 'nerf_losses'),
@@ -42,6 +44,9 @@ def main():
     ap.add_argument('--adam-grid', type=int, default=4194304, help='Grid_Size of the Adam launch on one hashed level')
     ap.add_argument('--levels-per-chunk', type=int, default=15, help='single-level scatter_kernel launches per backward chunk')
     ap.add_argument('--hashed-per-chunk', type=int, default=11, help='of which hashed levels (issued first)')
+    ap.add_argument('--binned-item-bytes', type=float, default=15 * 8 * 524288 * 10.0,
+                    help='bytes of corner-update items the binned update kernel reads per launch (2- and 8-byte loads, '
+                         'counted in full by FETCH_SIZE, unlike its 16-byte p/m/v stream which is counted at one half)')
     ap.add_argument('dirs', nargs='+')
     a = ap.parse_args()
     tot = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -74,6 +79,8 @@ def main():
                     cls = 'nerf_hashgrid_scatter[1 hashed level]' if pos < a.hashed_per_chunk else 'nerf_hashgrid_scatter[1 dense level]'
                 elif re.search(r'adam_kernel', kn) and grid == a.adam_grid:
                     cls = 'adam_table_slice'
+                elif re.search(r'table_update_kernel', kn):
+                    cls = 'nerf_table_update_binned'
                 if cls:
                     per_launch[cls][row['Counter_Name']].append(float(row['Counter_Value']) * 1024)
     pl = {}
@@ -83,6 +90,8 @@ def main():
         if cls == 'adam_table_slice':
             fetch *= 2
             cls = 'nerf_adam_step[table slice]'      # one hashed level: 2^T entries x F floats
+        if cls == 'nerf_table_update_binned':        # wide p/m/v stream counted at one half, the item reads in full
+            fetch = 2 * max(0.0, fetch - a.binned_item_bytes) + min(fetch, a.binned_item_bytes)
         pl[cls] = {'hbm_bytes': fetch + write, 'fetch_bytes': fetch, 'write_bytes': write}
     out = {'per_launch': pl}
     for entry in tot:

@@ -1,8 +1,8 @@
 set -o pipefail
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r01d; mkdir -p $O
+R=$GRAFT_REPO_ROOT; TAG=${TAG:-r01e}; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R && timeout -k 10 240 python bench.py > $O/bench.json 2> $O/bench.err || exit 1
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o r01d -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-render > $O/bench_under_rocprof.json 2> $O/prof.err || exit 2
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o prof -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-render > $O/bench_under_rocprof.json 2> $O/prof.err || exit 2
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_f -o f -- python $R/bench.py --steps 2 --warmup 2 --profile-steps 0 --no-cpu-baseline --no-render > $O/pmc_f.log 2>&1 || exit 3
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_w -o w -- python $R/bench.py --steps 2 --warmup 2 --profile-steps 0 --no-cpu-baseline --no-render > $O/pmc_w.log 2>&1 || exit 4
 cd $R && python tools/pmc_summary.py --steps 4 --out $O/traffic.json $O/pmc_f $O/pmc_w > $O/pmc_traffic.txt
