@@ -125,6 +125,11 @@ struct PointIn {
     int64_t n;         // image index
 };
 
+// Every operation is an explicitly rounded intrinsic (IEEE add / mul / div / sqrt, nothing the compiler may contract,
+// reassociate or turn into a reciprocal multiply): the kernels that visit a point -- forward gather, gradient scatter,
+// and above all the count and fill passes of the binned table update, which must agree on the table entry of every
+// corner -- all derive bit-identical coordinates from the same inputs.  (With plain `/` the LDS-sorted fill kernel
+// and the count kernel disagreed in the last bit of x for ~3 % of the contracted points.)
 __device__ __forceinline__ PointIn fetch_point(const NerfPointSrc& s, int64_t p, bool want_dir) {
     PointIn q;
     float x, y, z;
@@ -146,21 +151,21 @@ __device__ __forceinline__ PointIn fetch_point(const NerfPointSrc& s, int64_t p,
         y = __fadd_rn(s.rays_o[r * 3 + 1], __fmul_rn(ry, zv));
         z = __fadd_rn(s.rays_o[r * 3 + 2], __fmul_rn(rz, zv));
         q.ux = x; q.uy = y; q.uz = z;
-        const float rr = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z)));
+        const float rr = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z)));
         if (rr > s.inner_bound) {  // renderer.py:64-68
-            const float sc = (s.outer_bound - (s.outer_bound - s.inner_bound) / rr) / rr;
+            const float sc = __fdiv_rn(__fsub_rn(s.outer_bound, __fdiv_rn(__fsub_rn(s.outer_bound, s.inner_bound), rr)), rr);
             x = __fmul_rn(x, sc); y = __fmul_rn(y, sc); z = __fmul_rn(z, sc);
         }
         if (want_dir) {
-            const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(rx, rx), __fmul_rn(ry, ry)), __fmul_rn(rz, rz)));
-            q.dx = rx / nrm; q.dy = ry / nrm; q.dz = rz / nrm;
+            const float nrm = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(rx, rx), __fmul_rn(ry, ry)), __fmul_rn(rz, rz)));
+            q.dx = __fdiv_rn(rx, nrm); q.dy = __fdiv_rn(ry, nrm); q.dz = __fdiv_rn(rz, nrm);
             q.n = s.n ? s.n[r] : 0;
         }
     }
-    const float two_ob = 2.f * s.outer_bound;
-    q.x = __fadd_rn(x, s.outer_bound) / two_ob;
-    q.y = __fadd_rn(y, s.outer_bound) / two_ob;
-    q.z = __fadd_rn(z, s.outer_bound) / two_ob;
+    const float two_ob = __fmul_rn(2.f, s.outer_bound);
+    q.x = __fdiv_rn(__fadd_rn(x, s.outer_bound), two_ob);
+    q.y = __fdiv_rn(__fadd_rn(y, s.outer_bound), two_ob);
+    q.z = __fdiv_rn(__fadd_rn(z, s.outer_bound), two_ob);
     return q;
 }
 
@@ -208,9 +213,9 @@ struct Corners {
 __device__ __forceinline__ Corners level_corners(const LevelP& lp, float x, float y, float z) {
     const float px = fmaf(x, lp.scale, 0.5f), py = fmaf(y, lp.scale, 0.5f), pz = fmaf(z, lp.scale, 0.5f);
     const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
-    const float wx = px - fx, wy = py - fy, wz = pz - fz;
+    const float wx = __fsub_rn(px, fx), wy = __fsub_rn(py, fy), wz = __fsub_rn(pz, fz);
     const uint32_t ix = (uint32_t)(int)fx, iy = (uint32_t)(int)fy, iz = (uint32_t)(int)fz;
-    const float ax[2] = {1.f - wx, wx}, ay[2] = {1.f - wy, wy}, az[2] = {1.f - wz, wz};
+    const float ax[2] = {__fsub_rn(1.f, wx), wx}, ay[2] = {__fsub_rn(1.f, wy), wy}, az[2] = {__fsub_rn(1.f, wz), wz};
     Corners c;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {

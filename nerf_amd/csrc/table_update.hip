@@ -12,6 +12,8 @@
 // Used for the levels that are large enough to fill many partitions (the hashed levels and the big dense ones); the
 // small dense levels keep the LDS-privatised scatter + nerf_adam_step (a level smaller than a partition would put
 // every item of the step into one bin).
+#include <stdlib.h>
+
 #include "adam_common.h"
 #include "field_common.h"
 
@@ -165,6 +167,113 @@ __global__ __launch_bounds__(kBinThreads) void bin_fill_kernel(GridDev g, NerfPo
     }
 }
 
+// pass 3, sorted: the same placement, but every round of kSortPts points (8 * kSortPts items) is first sorted by bin
+// in LDS (counting sort inside the workgroup) and then written out in bin order, so that the items a round adds to one
+// bin leave as one contiguous run per wave instruction instead of as single 2- and 8-byte stores at random times
+// (the plain kernel writes 2.0 GB for 0.63 GB of items -- partially filled lines are evicted and rewritten).
+// Dynamic LDS: cur[nb] | cnt[nb] | start[nb] | wave sums | staged dst (u32), idx (u16), values.
+constexpr int kSortPts = kBinThreads;       // one point per thread and round
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const uint32_t t = __shfl_up(v, off, kWave);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+template <int F>
+__global__ __launch_bounds__(kBinThreads) void bin_fill_sorted_kernel(GridDev g, NerfPointSrc src, BinPlan plan, int64_t M,
+                                                                      int nwg, uint32_t nb_max,
+                                                                      const uint32_t* __restrict__ offs,
+                                                                      const float* __restrict__ dfeat, int64_t stride,
+                                                                      uint16_t* __restrict__ item_idx,
+                                                                      float* __restrict__ item_val) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
+    constexpr int kItems = 8 * kSortPts;
+    uint32_t* cur = lds_u;
+    uint32_t* cnt = cur + nb_max;
+    uint32_t* start = cnt + nb_max;
+    uint32_t* wsum = start + nb_max;                      // kBinThreads / kWave wave totals
+    uint32_t* st_dst = wsum + kBinThreads / kWave;
+    float* st_val = (float*)(st_dst + kItems);
+    uint16_t* st_idx = (uint16_t*)(st_val + kItems * F);
+    const int slot = blockIdx.y, l = plan.level[slot];
+    const uint32_t nb = plan.nbins[slot];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const uint32_t* o = offs + plan.hist_off[slot] + (int64_t)blockIdx.x * nb;
+    for (uint32_t i = threadIdx.x; i < nb; i += kBinThreads) { cur[i] = o[i]; cnt[i] = 0u; }
+    __syncthreads();
+    const LevelP lp = plan_level(g, l);
+    const int col = plan.col[slot];
+    uint16_t* ii = item_idx + plan.item_off[slot];
+    float* iv = item_val + plan.item_off[slot] * F;
+    const int64_t p0 = (int64_t)blockIdx.x * kBinChunkPts;
+    const int64_t p1 = p0 + kBinChunkPts < M ? p0 + kBinChunkPts : M;
+    const uint32_t per = (nb + kBinThreads - 1) / kBinThreads;     // consecutive bins per thread in the scan
+    for (int64_t base = p0; base < p1; base += kSortPts) {
+        const int64_t p = base + threadIdx.x;
+        const bool live = p < p1;
+        uint32_t bin[8], rank[8], loc[8];
+        float val[8][F];
+        if (live) {
+            const PointIn q = fetch_point(src, p, false);
+            const Corners c = level_corners(lp, q.x, q.y, q.z);
+            float d[F];
+            const float* dp = dfeat + p * stride + col;
+#pragma unroll
+            for (int f = 0; f < F; ++f) d[f] = dp[f];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t fl = c.idx[k] * (uint32_t)F;
+                bin[k] = fl / kPartFloats;
+                loc[k] = fl % kPartFloats;
+                rank[k] = atomicAdd(&cnt[bin[k]], 1u);
+#pragma unroll
+                for (int f = 0; f < F; ++f) val[k][f] = c.w[k] * d[f];
+            }
+        }
+        __syncthreads();
+        // exclusive scan of cnt[0..nb) -> start
+        uint32_t mine = 0;
+        for (uint32_t j = 0; j < per; ++j) { const uint32_t b = threadIdx.x * per + j; if (b < nb) mine += cnt[b]; }
+        const uint32_t incl = wave_incl_scan(mine, lane);
+        if (lane == kWave - 1) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t run = incl - mine;
+        for (int w = 0; w < wave; ++w) run += wsum[w];
+        for (uint32_t j = 0; j < per; ++j) {
+            const uint32_t b = threadIdx.x * per + j;
+            if (b < nb) { start[b] = run; run += cnt[b]; }
+        }
+        __syncthreads();
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t s_ = start[bin[k]] + rank[k];
+                st_dst[s_] = cur[bin[k]] + rank[k];
+                st_idx[s_] = (uint16_t)loc[k];
+#pragma unroll
+                for (int f = 0; f < F; ++f) st_val[s_ * F + f] = val[k][f];
+            }
+        }
+        __syncthreads();
+        const int64_t n_live = (p1 - base < kSortPts ? p1 - base : kSortPts) * 8;
+        for (int s_ = threadIdx.x; s_ < n_live; s_ += kBinThreads) {
+            const uint32_t dst = st_dst[s_];
+            ii[dst] = st_idx[s_];
+            if (F == 2) *(f32x2*)(iv + (int64_t)dst * 2) = *(const f32x2*)(st_val + s_ * 2);
+            else {
+#pragma unroll
+                for (int f = 0; f < F; ++f) iv[(int64_t)dst * F + f] = st_val[s_ * F + f];
+            }
+        }
+        for (uint32_t i = threadIdx.x; i < nb; i += kBinThreads) { cur[i] += cnt[i]; cnt[i] = 0u; }
+        __syncthreads();
+    }
+}
+
 // pass 4: one workgroup per partition: sum the bin into LDS, then Adam over the partition with the gradient from LDS
 template <int F>
 __global__ __launch_bounds__(kUpdThreads) void table_update_kernel(GridDev g, BinPlan plan,
@@ -295,12 +404,26 @@ extern "C" int nerf_table_bin_levels(const NerfGridCfg* grid, const NerfPointSrc
     hipStream_t st = (hipStream_t)stream;
     const dim3 nb((unsigned)lay.nwg, (unsigned)plan.count);
     const int64_t M = src->n_points;
+    uint32_t nb_max = 0;
+    for (int i = 0; i < plan.count; ++i) nb_max = plan.nbins[i] > nb_max ? plan.nbins[i] : nb_max;
+    nb_max = (nb_max + 3u) & ~3u;            // keeps the staged arrays behind the counters 16-byte aligned
+    // LDS of the sorted fill pass: 3 arrays of nb_max counters, 16 wave sums, 8 * kSortPts staged items
+    const int sorted_lds = (int)((3 * (size_t)nb_max + kBinThreads / kWave) * 4 + (size_t)8 * kSortPts * (4 + 4 * F + 2));
+    const bool sorted = sorted_lds <= 150 * 1024 && !getenv("NERF_BIN_FILL_PLAIN");
 #define BIN_PASSES(FF)                                                                                                 \
     do {                                                                                                               \
         bin_count_kernel<FF><<<nb, kBinThreads, 0, st>>>(g, *src, plan, M, lay.nwg, hist);                             \
         bin_scan_kernel<<<(unsigned)plan.count, kBinThreads, 0, st>>>(plan, lay.nwg, hist, bin_start);                 \
-        bin_fill_kernel<FF><<<nb, kBinThreads, 0, st>>>(g, *src, plan, M, lay.nwg, hist, dfeat, dfeat_stride, item_idx,  \
-                                                        item_val);                                                     \
+        if (sorted) {                                                                                                  \
+            auto kern = bin_fill_sorted_kernel<FF>;                                                                    \
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, sorted_lds); \
+            if (e != hipSuccess) { nerf_set_error("nerf_table_bin_levels: LDS attribute: %s", hipGetErrorString(e)); return (int)e; } \
+            kern<<<nb, kBinThreads, sorted_lds, st>>>(g, *src, plan, M, lay.nwg, nb_max, hist, dfeat, dfeat_stride, item_idx, \
+                                                      item_val);                                                       \
+        } else {                                                                                                       \
+            bin_fill_kernel<FF><<<nb, kBinThreads, 0, st>>>(g, *src, plan, M, lay.nwg, hist, dfeat, dfeat_stride, item_idx, \
+                                                            item_val);                                                 \
+        }                                                                                                              \
     } while (0)
     switch (F) {
         case 1: BIN_PASSES(1); break;
