@@ -30,17 +30,31 @@ from . import parallel
 from ._lib import NerfColMap, NerfLevelSet, check, lib, ptr, stream
 
 
-def level_costs(cfg, world=8):
+def _binned_hashed():
+    """Whether the hashed levels take the binned update under level sharding (optim.FusedAdam.attach reads the same
+    switch; it must be set alike on every rank)."""
+    return os.environ.get('NERF_TABLE_BINNED_SHARDED', 'hashed') != '0'
+
+
+def level_costs(cfg, world=8, binned_hashed=None):
     """Cost (ms per step, MI355X, 4096 rays x 128 samples per rank) of owning a level in a world of `world` ranks,
     from tools/shard_emulate.py --per-level (profiles/r01_shard_emulate_w8.log):
 
         scatter  grows with the points of ALL ranks: 0.11 ms per 524 k points at the memory-side atomic rate whatever
-                 the level's size, 0.13 on the big dense levels (more same-line traffic), 0.044 on the small dense
-                 levels that the LDS-privatised kernel takes;
+                 the level's size, 0.09 on the big dense levels, 0.044 on the smallest dense levels (one LDS copy per
+                 workgroup) and 0.09 on the chunked ones of the LDS-privatised kernel (per-rank step times of two
+                 different assignments at world 8, tools/shard_step_emulate.py, solved for the levels);
         encode   (coarse + fine pass = 1.5 x the fine pass) likewise: 0.005 ms (L2-resident dense level) to 0.04 ms
                  (finest hashed level) per 524 k points;
         Adam     does not grow with the world: 32 B per float of the level at ~5.4 TB/s (0.2 ms for a hashed level).
+
+    With the binned update on the hashed levels (csrc/table_update.hip; tools/shard_step_emulate.py: a rank owning
+    two hashed levels 4.6 -> 3.95 ms per step at world 8) their "scatter" is the count / fill passes plus the item
+    reads of the update pass, 0.06 ms per 524 k points, and their Adam share 24 B per float (0.87 ms per hashed
+    level and step at world 8, whatever the level).
     """
+    if binned_hashed is None:
+        binned_hashed = _binned_hashed()
     out = []
     hashed = [l for l in range(cfg.n_levels) if cfg.hashed[l]]
     for l in range(cfg.n_levels):
@@ -49,10 +63,13 @@ def level_costs(cfg, world=8):
             scatter = 0.112
             encode = 0.019 + 0.021 * (l - hashed[0]) / max(1, len(hashed) - 1)
         else:
-            scatter = 0.044 if floats <= 2 * 32768 else (0.11 if floats <= 16 * 32768 else 0.13)
+            scatter = 0.044 if floats <= 2 * 32768 else (0.09 if floats <= 16 * 32768 else 0.09)
             encode = 0.005 + 0.007 * min(1.0, cfg.entries[l] / float(1 << 24))
         adam = floats * 32 / 5.4e9
-        out.append(world * (scatter + 1.5 * encode) + adam)
+        if cfg.hashed[l] and binned_hashed and floats > 16 * 32768:
+            scatter, adam = 0.06, floats * 24 / 5.0e9
+            encode = 0.015 + 0.010 * (l - hashed[0]) / max(1, len(hashed) - 1)
+        out.append(world * (scatter + 1.5 * encode) + adam + 0.12)     # + launches and exchange bookkeeping per level
     return out
 
 

@@ -31,7 +31,8 @@ class TablePipeline(object):
         self.binned_levels = []
         if binned:
             own = list(range(L)) if levels is None else sorted(levels)
-            self.binned_levels = [l for l in own if int(grid_cfg.entries[l]) * n_features > 16 * 32768]
+            self.binned_levels = [l for l in own if int(grid_cfg.entries[l]) * n_features > 16 * 32768
+                                  and (binned != 'hashed' or grid_cfg.hashed[l])]
             rest = [l for l in own if l not in self.binned_levels]
             if levels is not None:
                 levels = rest
@@ -174,12 +175,14 @@ class FusedAdam(torch.optim.Optimizer):
             sh = model.shard_levels(None if shard_levels is True else shard_levels)
             sh.force = True         # explicitly requested (or world > 1): also valid, if pointless, for one rank
             self._sharding = sh
-            # (the binned update stays off here by default: an owner sees the points of ALL ranks on a few levels, and
-            # the clustered points of a dense level then pile into a handful of partitions -- measured slower than the
-            # atomic scatter in tools/shard_step_emulate.py; NERF_TABLE_BINNED_SHARDED=1 turns it on)
+            # (an owner sees the points of ALL ranks on a few levels: the clustered points of a DENSE level then pile
+            # into a handful of partitions and the binned update gets slower than the atomic scatter, measured with
+            # tools/shard_step_emulate.py -- so only the hashed levels, whose partitions fill evenly, are binned here;
+            # NERF_TABLE_BINNED_SHARDED=0 / 1 turns it off / on for every large level)
+            mode = os.environ.get('NERF_TABLE_BINNED_SHARDED', 'hashed')
             model.table_pipeline = TablePipeline(model.encoder.cfg, model.encoder.cfg.n_features, levels=sh.mine,
                                                  reduce=False,
-                                                 binned=os.environ.get('NERF_TABLE_BINNED_SHARDED', '0') == '1')
+                                                 binned={'0': False, '1': True}.get(mode, 'hashed'))
             self._pipeline = model.table_pipeline
         elif pipeline:
             model.table_pipeline = TablePipeline(model.encoder.cfg, model.encoder.cfg.n_features)
