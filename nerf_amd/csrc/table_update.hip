@@ -21,13 +21,19 @@ int nerf_check_src(const char* fn, const NerfPointSrc* src, bool with_color);   
 
 namespace {
 
-constexpr int kPartFloats = 16384;        // floats of one table partition (64 KB of LDS in the update kernel)
+#ifndef NERF_PART_FLOATS
+#define NERF_PART_FLOATS 16384
+#endif
+#ifndef NERF_UPD_THREADS
+#define NERF_UPD_THREADS 1024
+#endif
+constexpr int kPartFloats = NERF_PART_FLOATS;   // floats of one table partition (64 KB of LDS in the update kernel)
 #ifndef NERF_BIN_CHUNK
 #define NERF_BIN_CHUNK 16384
 #endif
 constexpr int kBinChunkPts = NERF_BIN_CHUNK;   // points per workgroup of the count / fill passes
 constexpr int kBinThreads = 1024;
-constexpr int kUpdThreads = 512;
+constexpr int kUpdThreads = NERF_UPD_THREADS;
 constexpr int kMaxBinsPerLevel = 8192;    // LDS histogram of the count / fill passes: 32 KB
 
 struct BinPlan {
