@@ -27,7 +27,7 @@ ENTRY = [
     (r'encode_levels_kernel', 'nerf_hashgrid_encode_levels'),
     (r'adam_kernel', 'nerf_adam_step'),
     (r'table_update_kernel', 'nerf_table_update_binned'),
-    (r'bin_(count|scan|fill)_kernel', 'nerf_table_bin_levels'),
+    (r'bin_(count|scan|fill)(_sorted)?_kernel', 'nerf_table_bin_levels'),
     (r'composite_fwd_kernel', 'nerf_composite_fwd'),
     (r'composite_bwd_kernel', 'nerf_composite_bwd'),
     (r'losses_kernel', 'nerf_losses'),
