@@ -34,12 +34,12 @@ def _batches():
     return out
 
 
-def _train(rank, world):
+def _train(rank, world, log2_T=15):
     from nerf_amd import helpers, parallel
     from nerf_amd.nets import NeRFNetwork
     from nerf_amd.optim import FusedAdam
     from nerf_amd.renderer import NerfRenderer
-    net = NeRFNetwork(5, seed=1, **KW)
+    net = NeRFNetwork(5, seed=1, **dict(KW, encoding_log2_hashmap_size=log2_T))
     with torch.no_grad():
         net.encoder.params.mul_(1e3)
     R = NerfRenderer(net, 2, 2.5, [1.6, 4.8], [64], 128, 0.2)
@@ -61,38 +61,45 @@ def _train(rank, world):
         opt.step()
     if world > 1:
         assert (net.level_sharding is not None) == (os.environ.get('NERF_TABLE_PARALLEL') != '0')
+    if log2_T >= 19 and (world == 1 or net.level_sharding is not None):
+        # levels 5-7 are hashed and large enough for the binned table update (every rank together owns all three)
+        assert world > 1 or net.table_pipeline.binned_levels == [5, 6, 7], net.table_pipeline.binned_levels
+        assert all(l in (5, 6, 7) for l in net.table_pipeline.binned_levels)
     net.sync_table()
     torch.cuda.synchronize()
     return [p.detach().cpu() for p in (net.encoder.params, net.sigma_net.params, net.color_net.params, net.latent_emb)]
 
 
-def _worker(rank, world, port, q, mode):
+def _worker(rank, world, port, q, mode, log2_T):
     os.environ['NERF_TABLE_PARALLEL'] = '1' if mode == 'sharded' else '0'
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    out = _train(rank, world)
+    out = _train(rank, world, log2_T)
     if rank == 0:
         q.put([o.numpy() for o in out])
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('mode,world', [('dp', 2), ('sharded', 2), ('sharded', 3)])
-def test_multi_rank_training_matches_single_process(mode, world):
-    """world 3 puts a rank in the middle (remote points on both sides of its own block) and splits 8 levels 3/3/2."""
+@pytest.mark.parametrize('mode,world,log2_T', [('dp', 2, 15), ('sharded', 2, 15), ('sharded', 3, 15), ('sharded', 2, 19),
+                                               ('dp', 2, 19)])
+def test_multi_rank_training_matches_single_process(mode, world, log2_T):
+    """world 3 puts a rank in the middle (remote points on both sides of its own block) and splits 8 levels 3/3/2.
+    log2_T 19 makes levels 5-7 hashed and large: the single process and the level owners then take the binned table
+    update (csrc/table_update.hip), the replicated 'dp' ranks the scatter -> all-reduce -> Adam pipeline."""
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode, log2_T)) for r in range(world)]
     [p.start() for p in procs]
     got = q.get(timeout=150)
     [p.join(60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
-    want = _train(0, 1)
+    want = _train(0, 1, log2_T)
     for g, w, name in zip(got, want, ('table', 'sigma_net', 'color_net', 'latent')):
         # Adam divides by sqrt(v): elements whose gradient is ~0 amplify rounding differences between the two
         # reduction orders, so compare with an absolute bar at the scale of one update step (lr)
