@@ -23,13 +23,14 @@ from nerf_amd.optim import FusedAdam
 from nerf_amd.renderer import NerfRenderer
 from test_gpu_parity import NET_CFGS, _batch, _make_pair
 
-def train(shard):
-    net, _ = _make_pair(NET_CFGS["small"])
+def train(shard, cfg="small"):
+    net, _ = _make_pair(NET_CFGS[cfg])
     R = NerfRenderer(net, 2, 2.5, [1.6, 4.8], [64], 128, 0.2)
     opt = FusedAdam([{"params": list(net.encoder.parameters()) + [net.latent_emb], "lr": 2e-2},
                      {"params": list(net.sigma_net.parameters()) + list(net.color_net.parameters()), "lr": 1e-3}],
                     betas=(0.9, 0.99), eps=1e-15).attach(net, shard_levels=shard)
     assert (net.level_sharding is not None) == bool(shard)
+    assert bool(net.table_pipeline.binned_levels) == (cfg == "base19")    # sharded: the hashed levels; plain: all large ones
     n, h, w, K, E, bg, noise, gt = [t.cuda() for t in _batch(3, 96)]
     for _ in range(3):
         opt.zero_grad()
@@ -52,6 +53,14 @@ assert abs(l0 - l1) < 1e-5, (l0, l1)
 for a, b in zip(sharded, plain):
     assert float(((a - b).abs() > 1e-5).float().mean()) < 0.02
     assert float((a - b).abs().max()) < 2e-3
+# the same with levels large enough for the binned table update behind the sharded exchange (T = 2^19)
+l1, sharded = train(True, "base19")
+l0, plain = train(False, "base19")
+dist.barrier()
+assert abs(l0 - l1) < 1e-5, (l0, l1)
+for a, b in zip(sharded, plain):
+    assert float(((a - b).abs() > 1e-5).float().mean()) < 0.02
+    assert float((a - b).abs().max()) < 4e-2 + 1e-3      # a table entry whose tiny gradient flips sign moves by 2 lr
 # the helpers directly, incl. the empty own block of the list all-to-all
 x = torch.arange(12., device="cuda").view(4, 3)
 assert torch.equal(parallel.all_gather_rows(x), x)
