@@ -123,3 +123,52 @@ def test_binned_update_rejects_bad_arguments():
                                           1e-15, 0.0, 1, 1.0, stream()) != 0
     assert lib().nerf_table_update_binned(C.byref(cfg), C.byref(ls), 64, ptr(ws), n, ptr(p), ptr(p), ptr(p), 1e-2, 0.9, 0.99,
                                           1e-15, 0.0, 0, 1.0, stream()) != 0               # step must be >= 1
+
+
+def _accum_run(binned, monkeypatch, n_backward, discard_first=False):
+    """`n_backward` backward passes on different batches, then one optimizer step, in the given table mode."""
+    from nerf_amd import helpers
+    from nerf_amd.optim import FusedAdam
+    from nerf_amd.renderer import NerfRenderer
+    from test_gpu_parity import NET_CFGS, _batch, _make_pair
+    monkeypatch.setenv('NERF_TABLE_BINNED', binned)
+    net, _ = _make_pair(NET_CFGS['base19'])
+    R = NerfRenderer(net, 2, 2.5, [1.6, 4.8], [64], 128, 0.2)
+    opt = FusedAdam([{'params': list(net.encoder.parameters()) + [net.latent_emb], 'lr': 2e-2},
+                     {'params': list(net.sigma_net.parameters()) + list(net.color_net.parameters()), 'lr': 1e-3}],
+                    betas=(0.9, 0.99), eps=1e-8).attach(net)
+    assert bool(net.table_pipeline.binned_levels) == (binned == '1')
+    for step in range(2):
+        opt.zero_grad()
+        if discard_first and step == 0:
+            # a backward whose gradients are thrown away: zero_grad() without step() must drop the binned updates too
+            n, h, w, K, E, bg, noise, gt = [t.cuda() for t in _batch(40, 64)]
+            img, wts, zs, _ = R.render(n, h, w, K, E, bg, noise=noise)
+            helpers.fused_train_loss(img, gt, wts, zs, 1e-3, 1e-1)[0].backward()
+            opt._grads_cleared = False
+            opt.zero_grad()
+        for j in range(n_backward):
+            n, h, w, K, E, bg, noise, gt = [t.cuda() for t in _batch(20 + 3 * step + j, 64)]
+            img, wts, zs, _ = R.render(n, h, w, K, E, bg, noise=noise)
+            loss, _ = helpers.fused_train_loss(img, gt, wts, zs, 1e-3, 1e-1)
+            loss.backward()
+        opt.step()
+    torch.cuda.synchronize()
+    st = opt.state[net.encoder.params]
+    return net.encoder.params.detach().clone(), st['exp_avg'].clone(), st['exp_avg_sq'].clone()
+
+
+@pytest.mark.parametrize('n_backward,discard_first', [(2, False), (1, True)])
+def test_binned_mode_handles_gradient_accumulation_and_discarded_backward(n_backward, discard_first, monkeypatch):
+    """Two backward passes before one step (the binned mode falls back to the atomic scatter into param.grad), and a
+    backward that is discarded by zero_grad(): both must give what the scatter -> Adam mode gives.  eps = 1e-8 keeps
+    Adam from amplifying summation noise, so the tables are comparable entry by entry."""
+    p1, m1, v1 = _accum_run('1', monkeypatch, n_backward, discard_first)
+    p0, m0, v0 = _accum_run('0', monkeypatch, n_backward, discard_first)
+    # the second step's samples depend on the first step's parameters to the last bit, so a few hundred of the 16 M
+    # entries see other corner updates; a lost or doubled backward pass would be off by ~50 % everywhere
+    assert float(m0.abs().max()) > 0
+    for a, b in ((m1, m0), (v1, v0)):
+        assert float((a - b).norm() / b.norm()) < 1e-2
+        assert float(((a - b).abs() > 1e-4 * float(b.abs().max())).float().mean()) < 1e-3
+    assert float(((p1 - p0).abs() > 1e-5).float().mean()) < 1e-3
