@@ -42,7 +42,7 @@ def level_costs(cfg, world=8, binned_hashed=None):
 
         scatter  grows with the points of ALL ranks: 0.11 ms per 524 k points at the memory-side atomic rate whatever
                  the level's size, 0.09 on the big dense levels, 0.044 on the smallest dense levels (one LDS copy per
-                 workgroup) and 0.09 on the chunked ones of the LDS-privatised kernel (per-rank step times of two
+                 workgroup) and 0.05-0.12, growing with the number of LDS chunks, on the chunked ones of the LDS-privatised kernel (per-rank step times of two
                  different assignments at world 8, tools/shard_step_emulate.py, solved for the levels);
         encode   (coarse + fine pass = 1.5 x the fine pass) likewise: 0.005 ms (L2-resident dense level) to 0.04 ms
                  (finest hashed level) per 524 k points;
@@ -50,7 +50,7 @@ def level_costs(cfg, world=8, binned_hashed=None):
 
     With the binned update on the hashed levels (csrc/table_update.hip; tools/shard_step_emulate.py: a rank owning
     two hashed levels 4.6 -> 3.95 ms per step at world 8) their "scatter" is the count / fill passes plus the item
-    reads of the update pass, 0.06 ms per 524 k points, and their Adam share 24 B per float (0.87 ms per hashed
+    reads of the update pass, 0.055 ms per 524 k points, and their Adam share 24 B per float (0.87 ms per hashed
     level and step at world 8, whatever the level).
     """
     if binned_hashed is None:
@@ -63,13 +63,13 @@ def level_costs(cfg, world=8, binned_hashed=None):
             scatter = 0.112
             encode = 0.019 + 0.021 * (l - hashed[0]) / max(1, len(hashed) - 1)
         else:
-            scatter = 0.044 if floats <= 2 * 32768 else (0.09 if floats <= 16 * 32768 else 0.09)
+            scatter = 0.044 if floats <= 2 * 32768 else (0.05 + 0.07 * floats / (16 * 32768.0) if floats <= 16 * 32768 else 0.09)
             encode = 0.005 + 0.007 * min(1.0, cfg.entries[l] / float(1 << 24))
         adam = floats * 32 / 5.4e9
         if cfg.hashed[l] and binned_hashed and floats > 16 * 32768:
-            scatter, adam = 0.06, floats * 24 / 5.0e9
+            scatter, adam = 0.055, floats * 24 / 5.0e9
             encode = 0.015 + 0.010 * (l - hashed[0]) / max(1, len(hashed) - 1)
-        out.append(world * (scatter + 1.5 * encode) + adam + 0.12)     # + launches and exchange bookkeeping per level
+        out.append(world * (scatter + 1.5 * encode) + adam + 0.05)     # + launches and exchange bookkeeping per level
     return out
 
 
