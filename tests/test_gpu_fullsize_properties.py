@@ -151,3 +151,57 @@ def test_adam_closed_form_on_the_whole_table(scene):
     assert float(g.abs().max()) == 0                                        # cleared in the same pass
     torch.testing.assert_close(m[moved], 0.1 * gref[moved], rtol=1e-5, atol=0)
     torch.testing.assert_close(v[moved], 0.01 * gref[moved] ** 2, rtol=1e-5, atol=0)
+
+
+def test_binned_update_equals_scatter_at_full_size(scene):
+    """The binned table update on ALL large levels of the 2^24 table for the step's 524 288 sample points.  With
+    beta1 = 0 and zero initial moments the new exp_avg IS the summed gradient (x grad_scale), so it must equal the
+    atomic scatter entry by entry up to fp32 summation order; levels outside the set stay untouched; exp_avg_sq and
+    the parameters then follow Adam's closed form for one step."""
+    from nerf_amd._lib import NerfLevelSet, check, lib, ptr, stream
+    from nerf_amd.nets import make_point_src
+    net, R, (n, h, w, K, E, gt, bg, noise) = scene
+    cfg = net.encoder.cfg
+    F = cfg.n_features
+    rays_o, rays_d = R.get_rays(h, w, K, E)
+    _, z = R.efficient_sampling(rays_o, rays_d, SF, 0.2, noise=noise)
+    M = N_RAYS * SF
+    src = make_point_src(2.5, rays_o=rays_o, rays_d=rays_d, z=z, z_stride=SF, n_samples=SF, n_points=M, inner_bound=2.0)
+    g = torch.Generator(device='cuda').manual_seed(9)
+    D = torch.randn(M, cfg.n_levels * F, device='cuda', generator=g) * 1e-3
+    levels = [l for l in range(cfg.n_levels) if int(cfg.entries[l]) * F > 16 * 32768]
+    assert len(levels) == 15
+    ls = NerfLevelSet()
+    ls.count = len(levels)
+    for i, l in enumerate(levels):
+        ls.level[i] = l
+    S = torch.zeros_like(net.encoder.params)
+    check(lib().nerf_hashgrid_scatter(C.byref(cfg), C.byref(src), ptr(D), ptr(S), 0, cfg.n_levels, stream()), 'scatter')
+    p0 = net.encoder.params.detach()
+    p, m, v = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    nbytes = lib().nerf_table_bin_workspace_bytes(C.byref(cfg), C.byref(ls), M)
+    assert nbytes > 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+    cols = (C.c_int32 * len(levels))(*[l * F for l in levels])
+    check(lib().nerf_table_bin_levels(C.byref(cfg), C.byref(src), C.byref(ls), ptr(D), D.shape[1], cols, ptr(ws), nbytes,
+                                      stream()), 'bin')
+    lr, b2, eps, gs = 1e-2, 0.99, 1e-8, 0.25
+    check(lib().nerf_table_update_binned(C.byref(cfg), C.byref(ls), M, ptr(ws), nbytes, ptr(p), ptr(m), ptr(v), lr, 0.0, b2,
+                                         eps, 0.0, 1, gs, stream()), 'update')
+    first = int(cfg.offset[levels[0]]) * F
+    smax = float(S.abs().max())
+    # small levels: untouched
+    assert torch.equal(p[:first], p0[:first]) and float(m[:first].abs().max()) == 0 and float(v[:first].abs().max()) == 0
+    # exp_avg == grad_scale * scatter
+    torch.testing.assert_close(m[first:], gs * S[first:], rtol=0, atol=2e-6 * gs * smax)
+    # exp_avg_sq and the parameter step in closed form (t = 1: bias corrections 1 - beta)
+    gr = gs * S[first:]
+    torch.testing.assert_close(v[first:], (1 - b2) * gr * gr, rtol=1e-4, atol=1e-6 * (gs * smax) ** 2)
+    want = p0[first:] - lr * gr / (gr.abs() + eps)          # m_hat / (sqrt(v_hat) + eps) with m_hat = g, v_hat = g^2
+    big = gr.abs() > 1e-3 * gs * smax                       # away from the sign flip of a noise-level gradient
+    torch.testing.assert_close(p[first:][big], want[big], rtol=0, atol=2e-3 * lr)
+    # sum of the corner updates is conserved level by level
+    for l in (5, 8, 9, 19):
+        a = int(cfg.offset[l]) * F
+        b = a + int(cfg.entries[l]) * F
+        assert abs(float(m[a:b].double().sum()) - gs * float(S[a:b].double().sum())) <= 1e-6 * gs * float(S[a:b].double().abs().sum())
