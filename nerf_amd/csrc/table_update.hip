@@ -105,7 +105,17 @@ __global__ __launch_bounds__(kBinThreads) void bin_scan_kernel(BinPlan plan, int
     for (uint32_t b0 = 0; b0 < nb; b0 += kBinThreads) {
         const uint32_t b = b0 + threadIdx.x;
         uint32_t tot = 0;
-        if (b < nb) for (int w = 0; w < nwg; ++w) tot += h[(int64_t)w * nb + b];
+        if (b < nb) {       // eight independent row reads in flight: the column walk is latency-bound otherwise
+            int w = 0;
+            for (; w + 8 <= nwg; w += 8) {
+                uint32_t t[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) t[k] = h[(int64_t)(w + k) * nb + b];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) tot += t[k];
+            }
+            for (; w < nwg; ++w) tot += h[(int64_t)w * nb + b];
+        }
         part[threadIdx.x] = tot;
         __syncthreads();
         for (int off = 1; off < kBinThreads; off <<= 1) {      // Hillis-Steele inclusive scan of this round's bin totals
@@ -118,7 +128,15 @@ __global__ __launch_bounds__(kBinThreads) void bin_scan_kernel(BinPlan plan, int
         uint32_t run = carry + part[threadIdx.x] - tot;         // first item of bin b
         if (b < nb) {
             bs[b] = run;
-            for (int w = 0; w < nwg; ++w) {
+            int w = 0;
+            for (; w + 8 <= nwg; w += 8) {
+                uint32_t t[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) t[k] = h[(int64_t)(w + k) * nb + b];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { h[(int64_t)(w + k) * nb + b] = run; run += t[k]; }
+            }
+            for (; w < nwg; ++w) {
                 const uint32_t c = h[(int64_t)w * nb + b];
                 h[(int64_t)w * nb + b] = run;
                 run += c;
