@@ -35,6 +35,7 @@ constexpr int kBinChunkPts = NERF_BIN_CHUNK;   // points per workgroup of the co
 constexpr int kBinThreads = 1024;
 constexpr int kUpdThreads = NERF_UPD_THREADS;
 constexpr int kMaxBinsPerLevel = 8192;    // LDS histogram of the count / fill passes: 32 KB
+static_assert(kPartFloats % 4 == 0 && kPartFloats <= 65536, "an item's partition-local offset is stored as uint16");
 
 struct BinPlan {
     int count;
@@ -303,8 +304,9 @@ template <int F>
 __global__ __launch_bounds__(kUpdThreads) void table_update_kernel(GridDev g, BinPlan plan,
                                                                    const uint32_t* __restrict__ bin_start,
                                                                    const uint16_t* __restrict__ item_idx,
-                                                                   const float* __restrict__ item_val, float* __restrict__ p,
-                                                                   float* __restrict__ m, float* __restrict__ v, AdamK k) {
+                                                                   const float* __restrict__ item_val, int64_t n_items_level,
+                                                                   float* __restrict__ p, float* __restrict__ m,
+                                                                   float* __restrict__ v, AdamK k) {
     extern __shared__ __attribute__((aligned(16))) float acc[];
     const uint32_t part = blockIdx.x;
     int slot = 0;
@@ -320,9 +322,13 @@ __global__ __launch_bounds__(kUpdThreads) void table_update_kernel(GridDev g, Bi
     for (int i = threadIdx.x; i < kPartFloats / 4; i += kUpdThreads) acc4[i] = zero;
     __syncthreads();
     const uint32_t* bs = bin_start + plan.part_base[slot] + slot;
-    const int64_t i0 = plan.item_off[slot] + bs[bin], i1 = plan.item_off[slot] + bs[bin + 1];
+    // (clamped: a workspace that was not filled for these levels / this point count must not turn into wild reads)
+    const uint32_t n_items = (uint32_t)n_items_level;
+    const uint32_t b0 = bs[bin] < n_items ? bs[bin] : n_items, b1 = bs[bin + 1] < n_items ? bs[bin + 1] : n_items;
+    const int64_t i0 = plan.item_off[slot] + b0, i1 = plan.item_off[slot] + (b1 > b0 ? b1 : b0);
     for (int64_t i = i0 + threadIdx.x; i < i1; i += kUpdThreads) {
-        const int li = item_idx[i];
+        int li = item_idx[i];
+        li = li <= kPartFloats - F ? li : kPartFloats - F;
         if (F == 2) {
             const f32x2 t = *(const f32x2*)(item_val + i * 2);
             atomicAdd(acc + li, t.x);
@@ -485,7 +491,8 @@ extern "C" int nerf_table_update_binned(const NerfGridCfg* grid, const NerfLevel
         auto kern = table_update_kernel<FF>;                                                                           \
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);  \
         if (e != hipSuccess) { nerf_set_error("nerf_table_update_binned: LDS attribute: %s", hipGetErrorString(e)); return (int)e; } \
-        kern<<<nb, kUpdThreads, lds_bytes, st>>>(g, plan, bin_start, item_idx, item_val, table, exp_avg, exp_avg_sq, k); \
+        kern<<<nb, kUpdThreads, lds_bytes, st>>>(g, plan, bin_start, item_idx, item_val, 8 * n_points, table, exp_avg,   \
+                                                 exp_avg_sq, k); \
     } while (0)
     switch (grid->n_features) {
         case 1: UPDATE(1); break;

@@ -172,3 +172,28 @@ def test_binned_mode_handles_gradient_accumulation_and_discarded_backward(n_back
         assert float((a - b).norm() / b.norm()) < 1e-2
         assert float(((a - b).abs() > 1e-4 * float(b.abs().max())).float().mean()) < 1e-3
     assert float(((p1 - p0).abs() > 1e-5).float().mean()) < 1e-3
+
+
+def test_update_on_a_foreign_workspace_stays_in_bounds():
+    """nerf_table_update_binned on a workspace that nerf_table_bin_levels never filled (random bytes): the result is
+    garbage, but every read and write stays inside the workspace and the listed levels (no GPU fault, levels outside
+    the set untouched)."""
+    from nerf_amd._lib import check, lib, ptr, stream
+    enc = _grid(16, 2, 16)
+    cfg = enc.cfg
+    levels = [15, 9]
+    ls = _level_set(levels)
+    M = 3000
+    n = lib().nerf_table_bin_workspace_bytes(C.byref(cfg), C.byref(ls), M)
+    ws = torch.randint(0, 256, (n,), dtype=torch.uint8, device='cuda', generator=torch.Generator(device='cuda').manual_seed(1))
+    p = enc.params.detach().clone()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    check(lib().nerf_table_update_binned(C.byref(cfg), C.byref(ls), M, ptr(ws), n, ptr(p), ptr(m), ptr(v), 1e-2, 0.9, 0.99,
+                                         1e-8, 0.0, 1, 1.0, stream()), 'update')
+    torch.cuda.synchronize()
+    untouched = torch.ones_like(p, dtype=torch.bool)
+    for l in levels:
+        a = int(cfg.offset[l]) * 2
+        untouched[a:a + int(cfg.entries[l]) * 2] = False
+    assert torch.equal(p[untouched], enc.params.detach()[untouched])
+    assert float(m[untouched].abs().max()) == 0
