@@ -2,6 +2,8 @@
 // full field, SH + latent + colour MLP) in one kernel.  The encoding is written straight into
 // the MFMA B operand of the first layer; weights stay in LDS, activations in registers.
 // Replaces NeRFNetwork.forward / .density (nets.py:109-164) and the tcnn objects they call.
+#include <stdlib.h>
+
 #include "field_common.h"
 
 namespace {
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(kSmallThreads) void scatter_small_kernel(GridDev g,
                                                                       const float* __restrict__ x01,
                                                                       const float* __restrict__ dfeat, int64_t M,
                                                                       float* __restrict__ dtable, int l, int col0,
-                                                                      int64_t stride, int chunk_entries, int transpose) {
+                                                                      int64_t stride, int chunk_entries, int transpose, int run) {
     extern __shared__ __attribute__((aligned(16))) float acc[];
     const uint32_t res = g.res[l], entries = g.entries[l], res2 = res * res;
     const uint32_t lo = blockIdx.y * (uint32_t)chunk_entries;
@@ -203,6 +205,66 @@ __global__ __launch_bounds__(kSmallThreads) void scatter_small_kernel(GridDev g,
     for (uint32_t i = threadIdx.x; i < n_here * F; i += blockDim.x) acc[i] = 0.f;
     __syncthreads();
     const float sc = g.scale[l];
+    if (run > 1) {
+        // Rays mode, coarse level: a thread walks `run` consecutive samples of ONE ray and sums the corner updates of a
+        // cell in registers for as long as the samples stay in that cell (13 samples per cell on level 0, 3-4 on level
+        // 4): one round of 8 x F LDS atomics per visited cell instead of per sample.  Consecutive lanes take the same
+        // run of consecutive rays -- unrelated pixels, so their cells rarely coincide.
+        const int64_t S = src.n_samples, n_rays = M / S, runs_per_ray = S / run;
+        const int64_t total = n_rays * runs_per_ray;
+        for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t rblk = (int64_t)((uint64_t)v / (uint64_t)n_rays), ray = v - rblk * n_rays;
+            const int64_t p0 = ray * S + rblk * run;
+            uint32_t cx0 = 0xffffffffu, cy0 = 0, cz0 = 0;
+            float sum[8][F];
+            bool open = false;
+            for (int j = 0; j <= run; ++j) {
+                uint32_t ix = 0xfffffffeu, iy = 0, iz = 0;
+                float wx = 0.f, wy = 0.f, wz = 0.f, d[F];
+                if (j < run) {
+                    const PointIn q = fetch_point(src, p0 + j, false);
+                    const float px = fmaf(q.x, sc, 0.5f), py = fmaf(q.y, sc, 0.5f), pz = fmaf(q.z, sc, 0.5f);
+                    const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+                    wx = px - fx; wy = py - fy; wz = pz - fz;
+                    ix = (uint32_t)(int)fx; iy = (uint32_t)(int)fy; iz = (uint32_t)(int)fz;
+#pragma unroll
+                    for (int f = 0; f < F; ++f) d[f] = dfeat[(p0 + j) * stride + col0 + f];
+                }
+                if (open && (j == run || ix != cx0 || iy != cy0 || iz != cz0)) {      // leave the cell: flush its 8 corners
+                    const bool miss = cx0 < res && cy0 < res && (uint64_t)(cz0 + 3) * res2 <= entries &&
+                                      ((cz0 + 3) * res2 <= lo || cz0 * res2 >= lo + n_here);
+                    if (!miss) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            uint32_t idx = (cx0 + (k & 1)) + (cy0 + ((k >> 1) & 1)) * res + (cz0 + ((k >> 2) & 1)) * res2;
+                            if (idx >= entries) idx %= entries;
+                            const uint32_t rel = idx - lo;
+                            if (rel < n_here) {
+#pragma unroll
+                                for (int f = 0; f < F; ++f) atomicAdd(acc + rel * F + f, sum[k][f]);
+                            }
+                        }
+                    }
+                    open = false;
+                }
+                if (j < run) {
+                    if (!open) {
+                        cx0 = ix; cy0 = iy; cz0 = iz; open = true;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k)
+#pragma unroll
+                            for (int f = 0; f < F; ++f) sum[k][f] = 0.f;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float w = __fmul_rn(__fmul_rn((k & 1) ? wx : 1.f - wx, (k & 2) ? wy : 1.f - wy), (k & 4) ? wz : 1.f - wz);
+#pragma unroll
+                        for (int f = 0; f < F; ++f) sum[k][f] += w * d[f];
+                    }
+                }
+            }
+        }
+    } else {
     // Neighbouring samples of one ray fall into the same coarse cell, and ds_add_f32 serialises lanes that
     // hit one address: walk the points "transposed" (consecutive lanes = the same sample of consecutive rays).
     // Measured better than the natural order on every level this kernel takes (also the chunked ones).
@@ -237,6 +299,7 @@ __global__ __launch_bounds__(kSmallThreads) void scatter_small_kernel(GridDev g,
                 for (int f = 0; f < F; ++f) atomicAdd(acc + rel * F + f, w * d[f]);
             }
         }
+    }
     }
     __syncthreads();
     // flush; every block starts its sweep at a different place so that the blocks do not chase each other
@@ -433,6 +496,12 @@ static int launch_scatter(const NerfGridCfg* grid, const NerfPointSrc* src, cons
             plan.col[plan.count++] = col;
             continue;
         }
+        // rays mode: runs of consecutive samples per thread (scatter_small_kernel); NERF_SMALL_RUN=1 turns it off
+        static const int run_max = getenv("NERF_SMALL_RUN") ? atoi(getenv("NERF_SMALL_RUN")) : 16;
+        int run = 1;        // the longest power-of-two run that divides the ray and still leaves a thread for every lane
+        if (!x01 && s.mode == 1)
+            while (run * 2 <= run_max && s.n_samples % (run * 2) == 0 && n_points / (run * 2) >= (int64_t)kNumCU * kSmallThreads)
+                run *= 2;
         const int chunks = (int)ceil_div64(floats, kSmallLdsFloats);
         const int chunk_entries = (int)ceil_div64(grid->entries[l], chunks);
         const int lds_bytes = chunk_entries * F * (int)sizeof(float);
@@ -447,7 +516,7 @@ static int launch_scatter(const NerfGridCfg* grid, const NerfPointSrc* src, cons
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
             if (e != hipSuccess) { nerf_set_error("scatter: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }   \
             kern<<<nb, kSmallThreads, lds_bytes, st>>>(g, s, x01, dfeat, n_points, dtable, l, col, stride, chunk_entries,  \
-                                                       1);                                                \
+                                                       1, run);                                           \
         } while (0)
         switch (F) {
             case 1: LAUNCH_SMALL(1); break;
