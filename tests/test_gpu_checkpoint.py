@@ -8,7 +8,7 @@ pytestmark = pytest.mark.gpu
 from test_gpu_parity import NET_CFGS, _make_pair  # noqa: E402
 
 
-def _make_trainer():
+def _make_trainer(cfg='small'):
     from nerf_amd.loaders.procedural import ProceduralSceneLoader
     from nerf_amd.optim import FusedAdam
     from nerf_amd.renderer import NerfRenderer
@@ -23,7 +23,7 @@ def _make_trainer():
             self.counter += 1
             return super().get_random_batch(batch_size, device)
 
-    net, _ = _make_pair(NET_CFGS['small'])
+    net, _ = _make_pair(NET_CFGS[cfg])
     R = NerfRenderer(net, 2, 2.5, [1.6, 4.8], [64], 128, 0.2)
     loader = SeededLoader(7, 64, 64, seed=0, batch_seed=0)
     opt = FusedAdam([{'params': list(net.encoder.parameters()), 'lr': 2e-2}, {'params': [net.latent_emb], 'lr': 2e-2},
@@ -40,15 +40,18 @@ def _params(tr):
     return [p.detach().clone() for p in (m.encoder.params, m.sigma_net.params, m.color_net.params, m.latent_emb)]
 
 
-def test_resume_continues_like_uninterrupted_run(tmp_path):
-    a = _make_trainer()
+@pytest.mark.parametrize('cfg', ['small', 'base19'])
+def test_resume_continues_like_uninterrupted_run(tmp_path, cfg):
+    """'base19': levels large enough for the binned table update (no dense table gradient exists in that mode)."""
+    a = _make_trainer(cfg)
+    assert bool(a.model.table_pipeline.binned_levels) == (cfg == 'base19')
     a.train_epoch(3)
     path = str(tmp_path / 'ck.pth')
     a.save_checkpoint(path)
     a.train_epoch(2)
     want = _params(a)
 
-    b = _make_trainer()
+    b = _make_trainer(cfg)
     b.load_checkpoint(path)
     assert b.iter == 3
     b.dataloader.counter = b.iter
