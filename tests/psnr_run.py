@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""PSNR evidence on the procedural synthetic scene (run on the GPU box).
+"""PSNR evidence on the procedural synthetic scene (run on the GPU box; lives under tests/ because it checks the HIP path against the CPU oracle -- test infrastructure, not collected by pytest).
 
  (1) quality: train the HIP path on ground-truth images rendered from an analytic field and report the PSNR of a
      training view (how the reference validates, trainer.py:95-101);
  (2) PSNR delta: train the HIP path and the CPU oracle from identical weights on identical batches / noise for the
      same budget and compare loss curves and final PSNR.
 
-    python tools/psnr_run.py --out profiles/psnr_r01.json
+    python tests/psnr_run.py --out profiles/psnr_r01.json
 """
 import argparse
 import json
