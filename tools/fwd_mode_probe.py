@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""Why does nerf_field_fwd run at 0.49 ms in some processes and 0.65 ms in others?  Times the fused forward of the
-bench configuration in isolation under a few suspected conditions."""
+"""Why did nerf_field_fwd run at 0.49 ms inside the training loop and at 0.68 ms everywhere else?  Times the fused
+forward of the bench configuration in isolation under the suspected conditions (allocator state, cache contents, busy
+or idle GPU before it, training steps before it).  Answer: none of them -- 0.68 ms is the kernel's
+time on an untrained or correctly trained table; the 0.49 ms came from a table damaged by the first-step Adam-moment
+race, whose exploded entries collapsed part of the fine samples and made the gathers more local."""
 import os
 import sys
 import time
