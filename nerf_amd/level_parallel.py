@@ -326,7 +326,7 @@ class LevelSharding(object):
             from .nets import make_point_src
             pipe.keep += [recv, src_all]
             pipe.bin(self.cfg, make_point_src(**self._sub_src(src_all, 0, W, M)), recv, wm,
-                     {l: slot[l] * self.F for l in binned}, dtable)
+                     {l: slot[l] * self.F for l in binned}, dtable, keepalive=src_all)
 
     # ---- table consistency ---------------------------------------------------------------
     def level_slice(self, l):

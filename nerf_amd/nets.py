@@ -226,12 +226,12 @@ class _FieldFn(torch.autograd.Function):
                 with torch.cuda.stream(pipe.scatter_stream):
                     pipe.scatter_stream.wait_event(done)
                     net.scatter_levels_pipelined(src, dfeat, dtable, final=True)
-            pipe.bin(net.encoder.cfg, src, dfeat, dfeat.shape[1], net.encoder.level_cols, dtable)
+            pipe.bin(net.encoder.cfg, src, dfeat, dfeat.shape[1], net.encoder.level_cols, dtable, keepalive=ctx.src_kwargs)
         elif pipe is None or not direct or cut * unit < 65536 or (rows - cut) * unit < 65536:
             check(lib().nerf_field_bwd(C.byref(net.encoder.cfg), C.byref(net.net_cfg), ptr(table), ptr(sigma_w), ptr(color_w),
                                        ptr(latent), net.N, C.byref(src), ptr(xh), ptr(dsigma), ptr(drgb),
                                        ptr(dfeat), None, ptr(dsw), ptr(dcw), ptr(dlat), stream()), 'nerf_field_bwd')
-            net.scatter_table(src, dfeat, dtable)
+            net.scatter_table(src, dfeat, dtable, keepalive=ctx.src_kwargs)
         else:
             # Two chunks of rays: the table scatter of the first (bound by memory-side atomics) runs on its own
             # stream underneath the MLP backward of the second (bound by the matrix cores).
@@ -400,7 +400,7 @@ class NeRFNetwork(nn.Module):
                     p.grad = torch.zeros_like(p)
         self.direct_grads = bool(on)
 
-    def scatter_table(self, src, dfeat, dtable):
+    def scatter_table(self, src, dfeat, dtable, keepalive=None):
         """dtable += scatter(dfeat).  With a table pipeline attached (FusedAdam.attach) the scatter is issued
         level by level, big hashed levels first, with an event after each level so that the optimizer (and,
         under data parallelism, the gradient all-reduce) of a level can start while later levels still scatter."""
@@ -412,7 +412,7 @@ class NeRFNetwork(nn.Module):
             return
         pipe.begin(dtable)
         self.scatter_levels_pipelined(src, dfeat, dtable, final=True)
-        pipe.bin(cfg, src, dfeat, dfeat.shape[1], self.encoder.level_cols, dtable)
+        pipe.bin(cfg, src, dfeat, dfeat.shape[1], self.encoder.level_cols, dtable, keepalive=keepalive)
 
     def scatter_levels_pipelined(self, src, dfeat, dtable, final):
         """One pass over the pipeline's level groups on the current stream; `final` marks the last part of the

@@ -80,10 +80,11 @@ class TablePipeline(object):
         self.keep = []
 
     # ---- binned levels ---------------------------------------------------------------------------------
-    def bin(self, cfg, src, dfeat, stride, cols, dtable):
+    def bin(self, cfg, src, dfeat, stride, cols, dtable, keepalive=None):
         """Sort the corner updates of this backward pass into table partitions (no optimizer hyper-parameters needed
         yet; FusedAdam.step applies them with nerf_table_update_binned).  `cols`: {level: first gradient column in a
-        row of dfeat}.  One backward per step is the fast path: a second backward before step() -- gradient
+        row of dfeat}; `keepalive`: whatever owns the memory `src` points into (it must outlive this pass when a
+        later backward has to replay it).  One backward per step is the fast path: a second backward before step() -- gradient
         accumulation -- falls back to the atomic scatter into p.grad."""
         if not self.binned_levels:
             return
@@ -97,7 +98,7 @@ class TablePipeline(object):
             self.binned_set = ls
         if self.binned_pending is not None or self.binned_fallback:
             if self.binned_pending is not None:         # move the earlier pass's updates into the gradient
-                src0, dfeat0, stride0, cols0 = self.binned_keep
+                src0, dfeat0, stride0, cols0, _alive = self.binned_keep
                 self._scatter_classic(cfg, src0, dfeat0, stride0, cols0, dtable)
                 self.binned_pending = None
             self.binned_fallback = True
@@ -113,7 +114,7 @@ class TablePipeline(object):
                                           col_arr, ptr(self.binned_ws), self.binned_ws.numel(), stream()),
               'nerf_table_bin_levels')
         self.binned_pending = (src.n_points, self.binned_ws.numel())
-        self.binned_keep = (src, dfeat, stride, cols)
+        self.binned_keep = (src, dfeat, stride, cols, keepalive)
 
     def _scatter_classic(self, cfg, src, dfeat, stride, cols, dtable):
         import ctypes as C
