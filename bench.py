@@ -208,6 +208,8 @@ def main():
     ap.add_argument('--no-pipeline', action='store_true', help='dense table all-reduce + one Adam pass (no per-level pipeline)')
     ap.add_argument('--profile-steps', type=int, default=5)
     ap.add_argument('--table-log2', type=int, default=24, help='REHEARSAL ONLY: smaller hash table (the metric config is 24)')
+    ap.add_argument('--levels', type=int, default=20, help='REHEARSAL ONLY: hash-grid levels (the metric config is 20; '
+                    "SURVEY's light variant is --levels 16 --table-log2 19)")
     ap.add_argument('--coarse', default='64', help="coarse sampling: '64' (metric config, z_bounds [1.6,4.8]) or "
                     "'480' (config_base: steps [256,128,64,32], z_bounds [.1,1,10,100,1000]; SURVEY C1/C4 parity sizes)")
     ap.add_argument('--hang-trace', type=int, default=0, help='dump all Python stacks to stderr every N seconds')
@@ -227,6 +229,7 @@ def main():
     import torch.distributed as dist
 
     NET['encoding_log2_hashmap_size'] = args.table_log2
+    NET['encoding_n_levels'] = args.levels
     if args.coarse == '480':
         STEPS[:] = [256, 128, 64, 32]
         Z_BOUNDS[:] = [0.1, 1, 10, 100, 1000]
@@ -315,9 +318,9 @@ def main():
             else:
                 bytes_step = n_items * (2 + 4 * F_) + n_pts_scatter * len(pipe.binned_levels) * 4 * F_
         elif base == 'nerf_hashgrid_encode_levels':
-            bytes_step = algorithmic_bytes(base, args.rays, n_params, Sc=sum(STEPS))   # both launches of one step together
+            bytes_step = algorithmic_bytes(base, args.rays, n_params, Sc=sum(STEPS), L=args.levels)   # both launches of one step together
         else:
-            b = algorithmic_bytes(base, args.rays, n_params, Sc=sum(STEPS))
+            b = algorithmic_bytes(base, args.rays, n_params, Sc=sum(STEPS), L=args.levels)
             bytes_step = b * (launches / args.profile_steps) if b else None
         k = {'name': name, 'launches_per_step': launches / args.profile_steps, 'ms_per_step': round(per_step_ms, 4),
              'avg_launch_ms': round(total_ms / launches, 4)}
@@ -388,8 +391,8 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': ('train step (render + backward + dense Adam), %d rays/GPU/step, %d coarse + 128 fine '
-                                    'samples/ray, config_base network (L20 F2 T%d, SH4, latent 48, 64-wide MLPs), '
-                                    'procedural scene 100 poses 800x800' % (args.rays, sum(STEPS), args.table_log2))
+                                    'samples/ray, config_base network (L%d F2 T%d, SH4, latent 48, 64-wide MLPs), '
+                                    'procedural scene 100 poses 800x800' % (args.rays, sum(STEPS), args.levels, args.table_log2))
                                    + ('' if args.coarse == '64' else ' [NOT the metric config: %s coarse samples]' % args.coarse),
                        'rays_per_gpu': args.rays, 'global_rays': args.rays * world, 'parallelism': ('dp%d over rays' % world) + (', hash table sharded by level (feature all-to-all)'
                                                                     if getattr(model_sharded, 'world', 1) > 1 else '') + fallback_note},
