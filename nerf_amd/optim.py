@@ -1,13 +1,14 @@
 """Fused dense Adam (nerf_adam_step) behind torch.optim's param_groups interface, so the
 reference's optimizer wiring (train.py:84-96: three groups, per-group lr / weight_decay,
 LambdaLR on top) works unchanged.  Update rule = torch.optim.Adam's single-tensor path."""
+import ctypes as C
 import os
 
 import torch
 import torch.distributed as dist
 
 from . import parallel
-from ._lib import check, lib, ptr, stream
+from ._lib import NerfLevelSet, check, lib, ptr, stream
 
 
 class TablePipeline(object):
@@ -88,8 +89,6 @@ class TablePipeline(object):
         accumulation -- falls back to the atomic scatter into p.grad."""
         if not self.binned_levels:
             return
-        import ctypes as C
-        from ._lib import NerfLevelSet
         if self.binned_set is None:
             ls = NerfLevelSet()
             ls.count = len(self.binned_levels)
@@ -117,8 +116,6 @@ class TablePipeline(object):
         self.binned_keep = (src, dfeat, stride, cols, keepalive)
 
     def _scatter_classic(self, cfg, src, dfeat, stride, cols, dtable):
-        import ctypes as C
-        from ._lib import NerfLevelSet
         for l in self.binned_levels:        # one level at a time: its columns start at cols[l] of every row
             one = NerfLevelSet()
             one.count = 1
@@ -264,7 +261,6 @@ class FusedAdam(torch.optim.Optimizer):
     def _binned_table_step(self, p, st, group, b1, b2, pipe):
         """The levels that go through the binned update: one pass that sums the step's corner updates per table
         partition in LDS and applies Adam (main stream; the small levels' scatter -> Adam runs beside it)."""
-        import ctypes as C
         cfg = self._model.encoder.cfg
         if pipe.binned_pending is not None:
             n_points, nbytes = pipe.binned_pending
