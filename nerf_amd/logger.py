@@ -35,10 +35,13 @@ class Logger(object):
         """name -> list of Python floats (this is where the deferred device->host copies happen)."""
         out = {}
         for k, vals in self._scalars.items():
-            if any(torch.is_tensor(v) for v in vals):
-                stacked = torch.stack([v.to(torch.float32).reshape(()) if torch.is_tensor(v) else torch.tensor(float(v))
-                                       for v in vals]).cpu()
-                self._scalars[k] = vals = stacked.tolist()
+            where = [i for i, v in enumerate(vals) if torch.is_tensor(v)]
+            if where:       # one device->host copy for the tensors logged since the last read; floats stay as they are
+                got = torch.stack([vals[i].to(torch.float32).reshape(()) for i in where]).cpu().tolist()
+                vals = list(vals)
+                for i, g in zip(where, got):
+                    vals[i] = g
+                self._scalars[k] = vals
             out[k] = [float(v) for v in vals]
         return out
 

@@ -25,3 +25,17 @@ def test_merge_and_dotlist():
     assert cfg.trainer.n_rays == 16384 and cfg.trainer.num_epochs == 2
     assert cfg.optimizer.net.lr == 5e-4 and cfg.optimizer.net.weight_decay == 1e-6
     assert cfg.scheduler == 'exp_decay' and cfg.renderer.importance_steps == 128
+
+
+def test_logger_scalars_mix_of_floats_and_tensors_read_twice():
+    """Logger.scalars is read once per epoch (trainer.py:57): values already converted to floats by an earlier read
+    and tensors logged since must mix (regression: torch.stack of CPU floats with device tensors)."""
+    import torch
+    from nerf_amd.logger import Logger
+    lg = Logger(None, verbose=False)
+    lg.scalar('loss', torch.tensor(1.5), 0)
+    lg.scalar('loss', 2.5, 1)
+    assert lg.scalars['loss'] == [1.5, 2.5]
+    lg.scalar('loss', torch.tensor(3.5), 2)
+    lg.scalar('lam', 0, 2)
+    assert lg.scalars['loss'] == [1.5, 2.5, 3.5] and lg.scalars['lam'] == [0.0]
