@@ -132,7 +132,14 @@ def cpu_baseline(n_rays=1024, steps=2, threads=16):
         t0 = time.perf_counter()
         R.render(n, h, w, K_all[n], E_all[n], bg)
         t_render = time.perf_counter() - t0
+    cpu_model = ''
+    try:
+        with open('/proc/cpuinfo') as f:
+            cpu_model = next((l.split(':', 1)[1].strip() for l in f if l.startswith('model name')), '')
+    except OSError:
+        pass
     return {'value': n_rays / t, 'unit': 'rays/s', 'cores': threads, 'kind': 'port', 'render_rays_per_s': n_rays / t_render,
+            'cpu_model': cpu_model, 'host_cpus': os.cpu_count(),
             'sample': '%d train steps of %d rays (1 warm-up), oracle/ref_cpu.py fp32 torch CPU, same network/renderer config'
                       % (steps, n_rays), 'seconds_per_step': t}
 
@@ -378,6 +385,15 @@ def main():
         _beat()
         render = {'workload': '800x800 image, 64+128 samples/ray, chunks of 65536 rays, sharded over %d GPU(s)' % world,
                   'rays_per_s': H * W / dt, 'ms_per_image': dt * 1e3}
+        # the reference's own chunk size (inference.py:66 uses trainer.n_rays-sized chunks; SURVEY C2 lists 16 384 too)
+        inf_small = Inferencer(renderer, 16384, 0, 0, 0.1, 0.05, 0.4, [1, 2, 3, 4], 20)
+        inf_small.render_image(n, h, w, K, E)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        inf_small.render_image(n, h, w, K, E)
+        torch.cuda.synchronize()
+        render['rays_per_s_chunks_16384'] = H * W / (time.perf_counter() - t2)
+        _beat()
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
