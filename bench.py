@@ -346,6 +346,14 @@ def main():
     def roofline_of(k):
         # HBM bytes per launch from the committed PMC passes (tools/pmc_summary.py), same launch class
         rec = pmc.get('per_launch', {}).get(k['name']) or pmc.get('per_launch', {}).get(k['name'].split(',')[0] + ']')
+        if k['name'].split('[')[0] == 'nerf_field_bwd':
+            # the MLP backward is bound by the matrix cores, not by its 336 B per point
+            return {'kernel': k['name'], 'bound': 'mfma', 'achieved': k.get('algorithmic_TFLOPs'),
+                    'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': k.get('mfma_f32_frac'),
+                    'traffic': rec['hbm_bytes'] if rec else None, 'avg_launch_ms': k['avg_launch_ms'],
+                    'launches_per_step': k['launches_per_step'],
+                    'algorithmic_flops_per_launch': algorithmic_flops('nerf_field_bwd', args.rays, Sc=sum(STEPS))
+                    / max(1.0, k['launches_per_step'])}
         return {'kernel': k['name'], 'bound': 'hbm', 'achieved': k.get('algorithmic_GBps'), 'peak': HBM_PEAK_GBS,
                 'unit': 'GB/s', 'frac': k.get('hbm_frac'), 'traffic': rec['hbm_bytes'] if rec else None,
                 'avg_launch_ms': k['avg_launch_ms'], 'launches_per_step': k['launches_per_step'],
