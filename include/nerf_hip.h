@@ -235,7 +235,8 @@ int nerf_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
  * 24 B of HBM traffic per parameter instead of 32 B, no memory-side atomics).  Levels must hold a multiple of 4 floats
  * at a 16-byte offset and at most 8192 partitions of 16 K floats (NERF_EUNSUPPORTED otherwise); meant for the hashed
  * and the large dense levels -- a level smaller than one partition works but serialises on one workgroup.
- * The caller owns the workspace; it must stay untouched between the two calls. */
+ * The caller owns the workspace; it must stay untouched between the two calls.  n_points == 0 is valid: nothing is
+ * sorted and the update is Adam with a zero gradient (the workspace is not read). */
 int64_t nerf_table_bin_workspace_bytes(const NerfGridCfg* grid, const NerfLevelSet* levels, int64_t n_points); /* < 0: error */
 /* dfeat_cols (host array of levels->count ints, nullable): first of the F gradient columns of levels->level[i] in a
  * row of dfeat; NULL = i*F (as in nerf_hashgrid_scatter_levels).  The full [M, L*F] matrix nerf_field_bwd writes

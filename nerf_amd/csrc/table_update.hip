@@ -324,7 +324,8 @@ __global__ __launch_bounds__(kUpdThreads) void table_update_kernel(GridDev g, Bi
     const uint32_t* bs = bin_start + plan.part_base[slot] + slot;
     // (clamped: a workspace that was not filled for these levels / this point count must not turn into wild reads)
     const uint32_t n_items = (uint32_t)n_items_level;
-    const uint32_t b0 = bs[bin] < n_items ? bs[bin] : n_items, b1 = bs[bin + 1] < n_items ? bs[bin + 1] : n_items;
+    uint32_t b0 = 0, b1 = 0;            // no points: a plain Adam step with a zero gradient, the workspace is not read
+    if (n_items) { b0 = bs[bin] < n_items ? bs[bin] : n_items; b1 = bs[bin + 1] < n_items ? bs[bin + 1] : n_items; }
     const int64_t i0 = plan.item_off[slot] + b0, i1 = plan.item_off[slot] + (b1 > b0 ? b1 : b0);
     for (int64_t i = i0 + threadIdx.x; i < i1; i += kUpdThreads) {
         int li = item_idx[i];
@@ -359,7 +360,7 @@ int make_plan(const char* fn, const NerfGridCfg* grid, const NerfLevelSet* level
     if (!grid || !levels || levels->count < 1 || levels->count > grid->n_levels || levels->count > NERF_MAX_LEVELS) {
         nerf_set_error("%s: bad level set", fn); return NERF_EINVAL;
     }
-    if (n_points < 1 || n_points >= (1ll << 28)) { nerf_set_error("%s: n_points must be in [1, 2^28)", fn); return NERF_EINVAL; }
+    if (n_points < 0 || n_points >= (1ll << 28)) { nerf_set_error("%s: n_points must be in [0, 2^28)", fn); return NERF_EINVAL; }
     const int F = grid->n_features;
     if (F != 1 && F != 2 && F != 4) { nerf_set_error("%s: unsupported: n_features_per_level must be 1, 2 or 4", fn); return NERF_EUNSUPPORTED; }
     if (grid->total_entries >= (1ull << 32)) { nerf_set_error("%s: bad grid", fn); return NERF_EINVAL; }
@@ -422,6 +423,7 @@ extern "C" int nerf_table_bin_levels(const NerfGridCfg* grid, const NerfPointSrc
     rc = make_plan("nerf_table_bin_levels", grid, levels, src->n_points, dfeat_cols, &plan, &lay);
     if (rc) return rc;
     NERF_REQUIRE(workspace_bytes >= lay.total && (((uintptr_t)workspace) & 15) == 0, "workspace too small or not 16-byte aligned");
+    if (src->n_points == 0) return 0;       // nothing to sort; nerf_table_update_binned(n_points = 0) reads no bins
     const int F = grid->n_features;
     for (int i = 0; i < plan.count; ++i)
         NERF_REQUIRE(dfeat_stride >= plan.col[i] + F, "dfeat_stride smaller than the last gradient column");

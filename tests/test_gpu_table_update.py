@@ -197,3 +197,39 @@ def test_update_on_a_foreign_workspace_stays_in_bounds():
         untouched[a:a + int(cfg.entries[l]) * 2] = False
     assert torch.equal(p[untouched], enc.params.detach()[untouched])
     assert float(m[untouched].abs().max()) == 0
+
+
+def test_binned_update_with_no_points_is_a_zero_gradient_adam_step():
+    """Empty input: nerf_table_bin_levels is a no-op and nerf_table_update_binned(n_points = 0) is Adam with g = 0 on
+    the listed levels (moments decay, parameters follow them), exactly what nerf_adam_step does with a zero gradient."""
+    from nerf_amd._lib import check, lib, ptr, stream
+    from nerf_amd.nets import make_point_src
+    enc = _grid(16, 2, 16)
+    cfg = enc.cfg
+    levels = [15, 9]
+    ls = _level_set(levels)
+    n = lib().nerf_table_bin_workspace_bytes(C.byref(cfg), C.byref(ls), 0)
+    assert n >= 0
+    ws = torch.empty(max(int(n), 256), dtype=torch.uint8, device='cuda')
+    x = torch.zeros(0, 3, device='cuda')
+    src = make_point_src(outer_bound=1.0, x=torch.zeros(1, 3, device='cuda'), n_points=0)
+    dfeat = torch.zeros(1, 4, device='cuda')
+    check(lib().nerf_table_bin_levels(C.byref(cfg), C.byref(src), C.byref(ls), ptr(dfeat), 4, None, ptr(ws), ws.numel(),
+                                      stream()), 'bin')
+    g = torch.Generator(device='cuda').manual_seed(2)
+    p0 = enc.params.detach().clone()
+    m0 = torch.randn(p0.shape, device='cuda', generator=g) * 1e-3
+    v0 = torch.rand(p0.shape, device='cuda', generator=g) * 1e-6
+    p, m, v = p0.clone(), m0.clone(), v0.clone()
+    hyper = (1e-2, 0.9, 0.99, 1e-8, 0.0)
+    check(lib().nerf_table_update_binned(C.byref(cfg), C.byref(ls), 0, ptr(ws), ws.numel(), ptr(p), ptr(m), ptr(v), *hyper, 5,
+                                         1.0, stream()), 'update')
+    pr, mr, vr = p0.clone(), m0.clone(), v0.clone()
+    gz = torch.zeros_like(p0)
+    for l in levels:
+        a = int(cfg.offset[l]) * 2
+        b = a + int(cfg.entries[l]) * 2
+        check(lib().nerf_adam_step(ptr(pr[a:b]), ptr(gz[a:b]), ptr(mr[a:b]), ptr(vr[a:b]), b - a, *hyper, 5, 1.0, 1, stream()),
+              'adam')
+    assert torch.equal(p, pr) and torch.equal(m, mr) and torch.equal(v, vr)
+    assert not torch.equal(p, p0)
