@@ -32,7 +32,8 @@ class TablePipeline(object):
         self.binned_levels = []
         if binned:
             own = list(range(L)) if levels is None else sorted(levels)
-            self.binned_levels = [l for l in own if int(grid_cfg.entries[l]) * n_features > 16 * 32768
+            # (upper bound: nerf_table_bin_levels takes at most 8192 partitions of 16 K floats per level)
+            self.binned_levels = [l for l in own if 16 * 32768 < int(grid_cfg.entries[l]) * n_features <= 8192 * 16384
                                   and (binned != 'hashed' or grid_cfg.hashed[l])]
             rest = [l for l in own if l not in self.binned_levels]
             if levels is not None:
