@@ -29,16 +29,18 @@ class ExtractDenseGeometry():
         dev = K.device
         mask_full = torch.zeros((res, res, res), dtype=torch.bool, device=dev)
         d = torch.linspace(-1, 1, res, device=dev)
-        Rinv = torch.inverse(E[:, None, None, :3, :3])
+        Rinv = torch.inverse(E[:, :3, :3])[:, None, None]                # [N,1,1,3,3]
+        Kb = K[:, None, None]
         for i in range(res):
             D = torch.stack(torch.meshgrid(d[i:i + 1], d, d, indexing='ij'), dim=-1)[0]
             inside = torch.linalg.norm(D, dim=-1) < 1
             rel = D[None] - E[:, None, None, :3, -1]
-            cam = Rinv @ rel[..., None]
-            pix_ = K[:, None, None, ...] @ cam
-            pix = pix_ / pix_[:, :, :, 2, None, :]
-            seen = ((pix[..., 0, 0] > 0) & (pix[..., 0, 0] < H) & (pix[..., 1, 0] > 0) & (pix[..., 1, 0] < W)
-                    & (pix_[..., 2, 0] > 0))
+            # the reference's two batched 3x3 mat-vecs (:41-43) as broadcast multiply + sum: a million tiny matmuls per
+            # slice took 46 ms in rocBLAS (5.9 s for the 128^3 mask, 23 x the 512^3 extraction that follows)
+            cam = (Rinv * rel[..., None, :]).sum(-1)                     # [N,res,res,3]
+            pix_ = (Kb * cam[..., None, :]).sum(-1)
+            pix = pix_ / pix_[..., 2:3]
+            seen = ((pix[..., 0] > 0) & (pix[..., 0] < H) & (pix[..., 1] > 0) & (pix[..., 1] < W) & (pix_[..., 2] > 0))
             mask_full[i] = inside & seen.any(dim=0)
         return mask_full
 
