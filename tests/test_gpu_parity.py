@@ -138,6 +138,8 @@ NET_CFGS = {
     'small': dict(encoding_n_levels=8, encoding_log2_hashmap_size=15),
     'odd': dict(encoding_n_levels=5, encoding_log2_hashmap_size=14),
     'base19': dict(encoding_n_levels=20, encoding_log2_hashmap_size=19),
+    'f4': dict(encoding_n_levels=8, encoding_log2_hashmap_size=15, encoding_n_features_per_level=4),
+    'f1': dict(encoding_n_levels=11, encoding_log2_hashmap_size=14, encoding_n_features_per_level=1),
 }
 
 
@@ -250,7 +252,7 @@ def test_adam_vs_torch():
         torch.testing.assert_close(pg.detach().cpu(), pc.detach(), rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize('name,binned', [('small', '1'), ('base19', '1'), ('base19', '0')])
+@pytest.mark.parametrize('name,binned', [('small', '1'), ('base19', '1'), ('base19', '0'), ('f4', '1'), ('f1', '1')])
 def test_train_steps_vs_oracle(name, binned, monkeypatch):
     """A short training trace (loss per step) of the HIP path against the CPU oracle:
     same rays, same noise, same init, Adam groups of train.py:84-88.  'base19' has levels large enough for the
@@ -292,7 +294,7 @@ def test_train_steps_vs_oracle(name, binned, monkeypatch):
         assert abs(a - b) <= 2e-4 * max(1.0, abs(b)), (lg, lo)
     # (lr 1e-3 x 4 steps: a weight whose tiny gradient flips sign with the summation order moves by up to 2 lr per step)
     torch.testing.assert_close(net.sigma_net.params.detach().cpu(), ora.sigma_params.detach(), rtol=0,
-                               atol=2e-3 if name == 'small' else 3e-3)
+                               atol=3e-3 if name == 'base19' else 2e-3)
     # Adam invariants of the table: a parameter that ever saw a gradient has both moments, and the moments agree with
     # the oracle's (torch.optim.Adam) wherever they are not summation noise.  (The first pipelined step once lost its
     # moments to a late zero-fill: v = 0 under m != 0 divides by eps on the next step.)
