@@ -140,6 +140,7 @@ NET_CFGS = {
     'base19': dict(encoding_n_levels=20, encoding_log2_hashmap_size=19),
     'f4': dict(encoding_n_levels=8, encoding_log2_hashmap_size=15, encoding_n_features_per_level=4),
     'f1': dict(encoding_n_levels=11, encoding_log2_hashmap_size=14, encoding_n_features_per_level=1),
+    'sh2lat16': dict(encoding_n_levels=8, encoding_log2_hashmap_size=15, encoding_dir_degree=2, latent_embedding_dim=16),
 }
 
 
@@ -154,7 +155,7 @@ def _make_pair(cfg, n_img=7, seed=3):
     ora = OracleNetwork(n_img, seed=seed, **kw)
     with torch.no_grad():
         ora.encoder_params.mul_(1e3)      # lift the table out of its 1e-4 init so features matter
-        ora.latent_emb.copy_(torch.randn(n_img, 48, generator=torch.Generator().manual_seed(seed)) * 0.3)
+        ora.latent_emb.copy_(torch.randn(n_img, kw["latent_embedding_dim"], generator=torch.Generator().manual_seed(seed)) * 0.3)
     net = NeRFNetwork(n_img, **kw)
     with torch.no_grad():
         assert net.encoder.params.numel() == ora.encoder_params.numel()
@@ -252,7 +253,7 @@ def test_adam_vs_torch():
         torch.testing.assert_close(pg.detach().cpu(), pc.detach(), rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize('name,binned', [('small', '1'), ('base19', '1'), ('base19', '0'), ('f4', '1'), ('f1', '1')])
+@pytest.mark.parametrize('name,binned', [('small', '1'), ('base19', '1'), ('base19', '0'), ('f4', '1'), ('f1', '1'), ('sh2lat16', '1')])
 def test_train_steps_vs_oracle(name, binned, monkeypatch):
     """A short training trace (loss per step) of the HIP path against the CPU oracle:
     same rays, same noise, same init, Adam groups of train.py:84-88.  'base19' has levels large enough for the
