@@ -92,8 +92,35 @@ def quality_run(res, n_img, L, T, iters, n_rays):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     p1 = eval_psnr(R, loader, n_img // 2)
+    # throughput on the TRAINED field (sparser sigma => other gather locality than the random-init bench)
+    def one_step(it):
+        opt.zero_grad()
+        n, h, w, K, E, gt, bg, _ = loader.get_random_batch(n_rays)
+        img, wts, zs, _ = R.render(n, h, w, K, E, bg)
+        loss, _ = helpers.fused_train_loss(img, gt, wts, zs, 1e-2, 1e-1)
+        loss.backward()
+        opt.step()
+    for it in range(5):
+        one_step(it)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(50):
+        one_step(it)
+    torch.cuda.synchronize()
+    ms_trained = (time.perf_counter() - t0) / 50 * 1e3
+    inf = Inferencer(R, 65536, 0, 0, 0.1, 0.05, 0.4, [1], 20)
+    views = [loader.get_image_batch(i) for i in range(16)]
+    inf.render_image(*views[0][:5])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for (n, h, w, K, E, _, _, _) in views:
+        inf.render_image(n, h, w, K, E)
+    torch.cuda.synchronize()
+    render_rps = 16 * res * res / (time.perf_counter() - t0)
     return {'config': 'L%d T%d, %d images %dx%d, %d iters x %d rays' % (L, T, n_img, res, res, iters, n_rays),
-            'psnr_before': p0, 'psnr_after': p1, 'train_seconds': dt, 'final_loss': float(loss)}
+            'psnr_before': p0, 'psnr_after': p1, 'train_seconds': dt, 'final_loss': float(loss),
+            'trained_ms_per_step': ms_trained, 'trained_train_rays_per_s': n_rays / ms_trained * 1e3,
+            'trained_render_rays_per_s_%dx%d_views' % (res, res): render_rps}
 
 
 def delta_run(res, n_img, L, T, iters, n_rays):
