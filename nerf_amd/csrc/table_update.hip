@@ -327,6 +327,8 @@ __global__ __launch_bounds__(kUpdThreads) void table_update_kernel(GridDev g, Bi
     uint32_t b0 = 0, b1 = 0;            // no points: a plain Adam step with a zero gradient, the workspace is not read
     if (n_items) { b0 = bs[bin] < n_items ? bs[bin] : n_items; b1 = bs[bin + 1] < n_items ? bs[bin + 1] : n_items; }
     const int64_t i0 = plan.item_off[slot] + b0, i1 = plan.item_off[slot] + (b1 > b0 ? b1 : b0);
+    // (several items per thread and round with their loads issued together measured no gain: two workgroups per CU
+    // already cover each other's latency in this phase)
     for (int64_t i = i0 + threadIdx.x; i < i1; i += kUpdThreads) {
         int li = item_idx[i];
         li = li <= kPartFloats - F ? li : kPartFloats - F;
@@ -344,7 +346,27 @@ __global__ __launch_bounds__(kUpdThreads) void table_update_kernel(GridDev g, Bi
     f4* p4 = (f4*)(p + base);
     f4* m4 = (f4*)(m + base);
     f4* v4 = (f4*)(v + base);
-    for (int i = threadIdx.x; i < n4; i += kUpdThreads) {
+    int i = threadIdx.x;
+    // a full partition is four quads per thread: all twelve loads are issued before the first Adam update (the step
+    // is 0.06 ms shorter than with one quad per loop round, although the kernel alone is 2 % slower)
+    for (; i + 3 * kUpdThreads < n4; i += 4 * kUpdThreads) {
+        f4 pq[4], mq[4], vq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            pq[u] = __builtin_nontemporal_load(p4 + i + u * kUpdThreads);
+            mq[u] = __builtin_nontemporal_load(m4 + i + u * kUpdThreads);
+            vq[u] = __builtin_nontemporal_load(v4 + i + u * kUpdThreads);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const f4 gq = acc4[i + u * kUpdThreads];
+            adam4(pq[u], gq, mq[u], vq[u], k);
+            __builtin_nontemporal_store(pq[u], p4 + i + u * kUpdThreads);
+            __builtin_nontemporal_store(mq[u], m4 + i + u * kUpdThreads);
+            __builtin_nontemporal_store(vq[u], v4 + i + u * kUpdThreads);
+        }
+    }
+    for (; i < n4; i += kUpdThreads) {
         f4 pa = __builtin_nontemporal_load(p4 + i), ma = __builtin_nontemporal_load(m4 + i);
         f4 va = __builtin_nontemporal_load(v4 + i);
         const f4 ga = acc4[i];
