@@ -384,12 +384,32 @@ int nerf_check_src(const char* fn, const NerfPointSrc* src, bool with_color) {
     return 0;
 }
 
-static unsigned fwd_grid(int64_t n_points, int lds_bytes) {
+// The forward kernels walk the tiles with a grid-sized stride, so the grid is what the chip holds at once: `per_cu`
+// resident workgroups per CU (registers and LDS, from the occupancy query) -- a larger grid runs as a full round of
+// workgroups followed by a partly filled one.
+static unsigned fwd_grid(int64_t n_points, int per_cu, bool color) {
     const int64_t tiles = ceil_div64(n_points, kTilePts);
-    const int per_cu = lds_bytes > 0 ? (int)((160 * 1024) / lds_bytes) : 8;
+    static const int forced = getenv("NERF_FWD_BLOCKS_PER_CU") ? atoi(getenv("NERF_FWD_BLOCKS_PER_CU")) : 0;
+    static const int forced_d = getenv("NERF_DENSITY_BLOCKS_PER_CU") ? atoi(getenv("NERF_DENSITY_BLOCKS_PER_CU")) : 0;
+    // two workgroups (eight waves) per CU measured best for both kernels: the density kernel could hold five, but runs
+    // 0.307 ms at two against 0.325 ms at five and 0.341 ms with a grid of eight per CU (more waves only thrash the L2
+    // with more random gathers in flight); NERF_FWD_BLOCKS_PER_CU / NERF_DENSITY_BLOCKS_PER_CU override for tuning
+    if (per_cu > 2) per_cu = 2;
+    if (color && forced > 0) per_cu = forced;
+    if (!color && forced_d > 0) per_cu = forced_d;
     const int64_t cap = (int64_t)kNumCU * (per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu));
     const int64_t want = ceil_div64(tiles, 4);
     return (unsigned)(want < cap ? want : cap);
+}
+
+template <typename K>
+static int resident_blocks_per_cu(K kern, int lds_bytes) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 256, (size_t)lds_bytes) != hipSuccess || n < 1) {
+        (void)hipGetLastError();
+        n = lds_bytes > 0 ? (160 * 1024) / lds_bytes : 8;      // LDS bound only
+    }
+    return n;
 }
 
 template <bool COLOR, bool FEATS>
@@ -399,13 +419,15 @@ static int launch_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const floa
     const GridDev g = make_grid_dev(grid);
     const NetLds s = make_net_lds(grid, net, COLOR);
     const int lds_bytes = s.total * (int)sizeof(float);
-    const unsigned nb = fwd_grid(src->n_points, lds_bytes);
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(FF)                                                                                                     \
     do {                                                                                                               \
         auto kern = field_fwd_kernel<FF, COLOR, FEATS>;                                                                     \
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);  \
         if (e != hipSuccess) { nerf_set_error("field_fwd: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }  \
+        static int per_cu = 0, per_cu_lds = -1;     /* per instantiation; the net shape rarely changes */              \
+        if (per_cu_lds != lds_bytes) { per_cu = resident_blocks_per_cu(kern, lds_bytes); per_cu_lds = lds_bytes; }     \
+        const unsigned nb = fwd_grid(src->n_points, per_cu, COLOR);                                                          \
         kern<<<nb, 256, lds_bytes, st>>>(g, s, table, sw, cw, latent, *src, sigma, rgb, xh, xyz, xh_in);               \
     } while (0)
     switch (grid->n_features) {
