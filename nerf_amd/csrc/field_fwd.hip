@@ -12,13 +12,13 @@ namespace {
 // FEATS: the hash-grid features come ready-made from xh_in (level-sharded table: the level owners encoded
 // them and an all-to-all brought them here) instead of being gathered from `table`.
 template <int F, bool COLOR, bool FEATS>
-__global__ __launch_bounds__(256) void field_fwd_kernel(GridDev g, NetLds s, const float* __restrict__ table,
+__global__ __launch_bounds__(512) void field_fwd_kernel(GridDev g, NetLds s, const float* __restrict__ table,
                                                         const float* __restrict__ sigma_w,
                                                         const float* __restrict__ color_w,
                                                         const float* __restrict__ latent, NerfPointSrc src,
                                                         float* __restrict__ sigma_out, float* __restrict__ rgb_out,
                                                         float* __restrict__ xh_out, float* __restrict__ xyz_out,
-                                                        const float* __restrict__ xh_in) {
+                                                        const float* __restrict__ xh_in, int stage_off) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     lds_load_net(lds, s, sigma_w, color_w, COLOR);
 
@@ -27,6 +27,11 @@ __global__ __launch_bounds__(256) void field_fwd_kernel(GridDev g, NetLds s, con
     const int64_t M = src.n_points;
     const int64_t n_tiles = (M + kTilePts - 1) / kTilePts;
     const int LF = g.L * F;
+    // x_hashtable rows of the tile are collected in a wave-private LDS area [32 points][L*F] (stage_off > 0) and leave as
+    // whole 16-byte pieces of one contiguous 32-row block: written level by level straight from the gather loop, every
+    // 160-byte row reached the L2 as twenty 8-byte pieces spread over the whole tile time and was evicted half filled
+    // several times (366 MB of HBM writes for 98 MB of output, 0.09 ms of the kernel)
+    float* stg = (!FEATS && xh_out && stage_off > 0) ? lds + stage_off + wave * (kTilePts * LF) : nullptr;
 
     for (int64_t tile = (int64_t)blockIdx.x * waves_per_block + wave; tile < n_tiles;
          tile += (int64_t)gridDim.x * waves_per_block) {
@@ -63,12 +68,36 @@ __global__ __launch_bounds__(256) void field_fwd_kernel(GridDev g, NetLds s, con
                 a0 = MFMA32(w1r0[j * F + f], b, a0);
                 a1 = MFMA32(w1r1[j * F + f], b, a1);
             }
-            if (!FEATS && xh_out && valid && lp.active) {
+            if (!FEATS && stg) {
+                if (lp.active) {
+                    float* dst = stg + l31 * LF + (h * g.LH + j) * F;
+                    if (F == 2) { f32x2 t; t.x = feat[0]; t.y = feat[F - 1]; *(f32x2*)dst = t; }
+                    else {
+#pragma unroll
+                        for (int f = 0; f < F; ++f) dst[f] = feat[f];
+                    }
+                }
+            } else if (!FEATS && xh_out && valid && lp.active) {
                 float* dst = xh_out + p * LF + (h * g.LH + j) * F;
                 if (F == 2) { f32x2 t; t.x = feat[0]; t.y = feat[F - 1]; *(f32x2*)dst = t; }
                 else if (F == 4) { f32x4 t; t.x = feat[0]; t.y = feat[1 % F]; t.z = feat[2 % F]; t.w = feat[3 % F]; *(f32x4*)dst = t; }
                 else dst[0] = feat[0];
             }
+        }
+        if (!FEATS && stg) {
+            // (LDS instructions of one wave complete in issue order: the rows written above are visible to the reads here,
+            // and the next tile's writes come after these reads)
+            __builtin_amdgcn_wave_barrier();
+            const int64_t first = tile * kTilePts;
+            const int n_rows = (int)(M - first < kTilePts ? M - first : kTilePts);
+            const int n_floats = n_rows * LF;
+            float* gdst = xh_out + first * LF;
+            if ((LF & 3) == 0 && ((((uintptr_t)xh_out) & 15) == 0)) {
+                for (int i = lane * 4; i < n_floats; i += 4 * kWave) *(f32x4*)(gdst + i) = *(const f32x4*)(stg + i);
+            } else {
+                for (int i = lane; i < n_floats; i += kWave) gdst[i] = stg[i];
+            }
+            __builtin_amdgcn_wave_barrier();
         }
         a0 = relu16(a0);
         a1 = relu16(a1);
@@ -387,7 +416,7 @@ int nerf_check_src(const char* fn, const NerfPointSrc* src, bool with_color) {
 // The forward kernels walk the tiles with a grid-sized stride, so the grid is what the chip holds at once: `per_cu`
 // resident workgroups per CU (registers and LDS, from the occupancy query) -- a larger grid runs as a full round of
 // workgroups followed by a partly filled one.
-static unsigned fwd_grid(int64_t n_points, int per_cu, bool color) {
+static unsigned fwd_grid(int64_t n_points, int per_cu, int waves_per_block, bool color) {
     const int64_t tiles = ceil_div64(n_points, kTilePts);
     static const int forced = getenv("NERF_FWD_BLOCKS_PER_CU") ? atoi(getenv("NERF_FWD_BLOCKS_PER_CU")) : 0;
     static const int forced_d = getenv("NERF_DENSITY_BLOCKS_PER_CU") ? atoi(getenv("NERF_DENSITY_BLOCKS_PER_CU")) : 0;
@@ -398,14 +427,14 @@ static unsigned fwd_grid(int64_t n_points, int per_cu, bool color) {
     if (color && forced > 0) per_cu = forced;
     if (!color && forced_d > 0) per_cu = forced_d;
     const int64_t cap = (int64_t)kNumCU * (per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu));
-    const int64_t want = ceil_div64(tiles, 4);
+    const int64_t want = ceil_div64(tiles, waves_per_block);
     return (unsigned)(want < cap ? want : cap);
 }
 
 template <typename K>
-static int resident_blocks_per_cu(K kern, int lds_bytes) {
+static int resident_blocks_per_cu(K kern, int threads, int lds_bytes) {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 256, (size_t)lds_bytes) != hipSuccess || n < 1) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, threads, (size_t)lds_bytes) != hipSuccess || n < 1) {
         (void)hipGetLastError();
         n = lds_bytes > 0 ? (160 * 1024) / lds_bytes : 8;      // LDS bound only
     }
@@ -418,7 +447,17 @@ static int launch_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const floa
                       const float* xh_in, void* stream) {
     const GridDev g = make_grid_dev(grid);
     const NetLds s = make_net_lds(grid, net, COLOR);
-    const int lds_bytes = s.total * (int)sizeof(float);
+    int lds_bytes = s.total * (int)sizeof(float);
+    // feature rows staged per wave (see the kernel): one 512-thread workgroup per CU instead of two of 256 threads, so
+    // that the weights are held once and 8 x [32][L*F] floats fit beside them
+    int threads = 256, stage_off = 0;
+    const int stage_wave_floats = kTilePts * grid->n_levels * grid->n_features;
+    if (!FEATS && xh && src->n_points >= (int64_t)kNumCU * 512 / 2) {
+        const int off = (s.total + 3) & ~3;
+        const int need = (off + 8 * stage_wave_floats) * (int)sizeof(float);
+        if (need <= 112 * 1024) { threads = 512; stage_off = off; lds_bytes = need; }
+    }
+    const int waves = threads / 64;
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(FF)                                                                                                     \
     do {                                                                                                               \
@@ -426,9 +465,9 @@ static int launch_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const floa
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);  \
         if (e != hipSuccess) { nerf_set_error("field_fwd: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }  \
         static int per_cu = 0, per_cu_lds = -1;     /* per instantiation; the net shape rarely changes */              \
-        if (per_cu_lds != lds_bytes) { per_cu = resident_blocks_per_cu(kern, lds_bytes); per_cu_lds = lds_bytes; }     \
-        const unsigned nb = fwd_grid(src->n_points, per_cu, COLOR);                                                          \
-        kern<<<nb, 256, lds_bytes, st>>>(g, s, table, sw, cw, latent, *src, sigma, rgb, xh, xyz, xh_in);               \
+        if (per_cu_lds != lds_bytes) { per_cu = resident_blocks_per_cu(kern, threads, lds_bytes); per_cu_lds = lds_bytes; } \
+        const unsigned nb = fwd_grid(src->n_points, threads == 512 ? (per_cu > 1 ? 1 : per_cu) : per_cu, waves, COLOR);   \
+        kern<<<nb, threads, lds_bytes, st>>>(g, s, table, sw, cw, latent, *src, sigma, rgb, xh, xyz, xh_in, stage_off); \
     } while (0)
     switch (grid->n_features) {
         case 1: LAUNCH(1); break;

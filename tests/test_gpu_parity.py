@@ -454,3 +454,34 @@ def test_module_level_composition_matches_fused_field():
         torch.testing.assert_close(a, b, rtol=1e-3, atol=2e-5 * s, msg=lambda m, w=name: w + ': ' + m)
     for p in params:
         p.grad = None
+
+
+@pytest.mark.parametrize('name,M', [('small', 65536 + 37), ('f1', 70001), ('odd', 65536 + 5), ('f4', 66000)])
+def test_feature_rows_of_large_batches(name, M):
+    """From 64 K points on, the fused forward collects the x_hashtable rows of a 32-point tile in LDS and writes them as
+    one contiguous block (16-byte pieces when L*F is a multiple of 4, single floats otherwise).  The rows must equal
+    those of the direct-store path bit for bit, including the ragged last tile, for forward() and density()."""
+    from nerf_amd.nets import NeRFNetwork
+    kw = dict(encoding_precision='float32', encoding_n_features_per_level=2, geo_feat_dim=15, sigma_hidden_dim=64,
+              sigma_num_layers=2, encoding_dir_precision='float32', encoding_dir_encoding='SphericalHarmonics',
+              encoding_dir_degree=4, latent_embedding_dim=48, color_hidden_dim=64, color_num_layers=3)
+    kw.update(NET_CFGS[name])
+    net = NeRFNetwork(5, seed=1, **kw)
+    g = torch.Generator().manual_seed(9)
+    with torch.no_grad():
+        net.encoder.params.copy_((torch.rand(net.encoder.params.shape, generator=g) - 0.5).cuda())
+        x = ((torch.rand(M, 3, generator=g) * 2 - 1) * 2.4).cuda()
+        d = torch.nn.functional.normalize(torch.randn(M, 3, generator=g), dim=-1).cuda()
+        n = torch.randint(0, 5, (M,), generator=g).cuda()
+        sigma, rgb, aux = net(x, d, n, 2.5)
+        # batches below 64 K points take the direct-store path: the same rows, bit for bit, whole batch covered
+        parts = [net(x[a:a + 30000], d[a:a + 30000], n[a:a + 30000], 2.5) for a in range(0, M, 30000)]
+        assert torch.equal(aux['x_hashtable'], torch.cat([p[2]['x_hashtable'] for p in parts]))
+        assert torch.equal(sigma, torch.cat([p[0] for p in parts]))
+        assert torch.equal(rgb, torch.cat([p[1] for p in parts]))
+        sigma_d, aux_d = net.density(x, 2.5)
+        assert torch.equal(aux_d['x_hashtable'], aux['x_hashtable'])
+        assert torch.equal(sigma_d, sigma)
+        # and the stand-alone encoder's (torch divides by the constant as a multiplication: last-bit input differences)
+        want = net.encoder((x + 2.5) / 5.0)
+        torch.testing.assert_close(aux['x_hashtable'], want, rtol=0, atol=2e-4)
