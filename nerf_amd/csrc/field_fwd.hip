@@ -250,33 +250,36 @@ __global__ __launch_bounds__(kSmallThreads) void scatter_small_kernel(GridDev g,
             for (int j = 0; j <= run; ++j) {
                 uint32_t ix = 0xfffffffeu, iy = 0, iz = 0;
                 float wx = 0.f, wy = 0.f, wz = 0.f, d[F];
+                bool have = false;      // a sample whose cell can touch this chunk (its gradient is only read then)
                 if (j < run) {
                     const PointIn q = fetch_point(src, p0 + j, false);
                     const float px = fmaf(q.x, sc, 0.5f), py = fmaf(q.y, sc, 0.5f), pz = fmaf(q.z, sc, 0.5f);
                     const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
                     wx = px - fx; wy = py - fy; wz = pz - fz;
                     ix = (uint32_t)(int)fx; iy = (uint32_t)(int)fy; iz = (uint32_t)(int)fz;
+                    // in-range cells put their 8 corners in [iz*res2, (iz+3)*res2): skip those whose z slab misses this
+                    // chunk (not near the wrap-around of the dense index at the top of the level, nor for stray points)
+                    have = !(ix < res && iy < res && (uint64_t)(iz + 3) * res2 <= entries &&
+                             ((iz + 3) * res2 <= lo || iz * res2 >= lo + n_here));
+                    if (have) {
 #pragma unroll
-                    for (int f = 0; f < F; ++f) d[f] = dfeat[(p0 + j) * stride + col0 + f];
+                        for (int f = 0; f < F; ++f) d[f] = dfeat[(p0 + j) * stride + col0 + f];
+                    }
                 }
-                if (open && (j == run || ix != cx0 || iy != cy0 || iz != cz0)) {      // leave the cell: flush its 8 corners
-                    const bool miss = cx0 < res && cy0 < res && (uint64_t)(cz0 + 3) * res2 <= entries &&
-                                      ((cz0 + 3) * res2 <= lo || cz0 * res2 >= lo + n_here);
-                    if (!miss) {
+                if (open && (!have || ix != cx0 || iy != cy0 || iz != cz0)) {      // leave the cell: flush its 8 corners
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) {
-                            uint32_t idx = (cx0 + (k & 1)) + (cy0 + ((k >> 1) & 1)) * res + (cz0 + ((k >> 2) & 1)) * res2;
-                            if (idx >= entries) idx %= entries;
-                            const uint32_t rel = idx - lo;
-                            if (rel < n_here) {
+                    for (int k = 0; k < 8; ++k) {
+                        uint32_t idx = (cx0 + (k & 1)) + (cy0 + ((k >> 1) & 1)) * res + (cz0 + ((k >> 2) & 1)) * res2;
+                        if (idx >= entries) idx %= entries;
+                        const uint32_t rel = idx - lo;
+                        if (rel < n_here) {
 #pragma unroll
-                                for (int f = 0; f < F; ++f) atomicAdd(acc + rel * F + f, sum[k][f]);
-                            }
+                            for (int f = 0; f < F; ++f) atomicAdd(acc + rel * F + f, sum[k][f]);
                         }
                     }
                     open = false;
                 }
-                if (j < run) {
+                if (have) {
                     if (!open) {
                         cx0 = ix; cy0 = iy; cz0 = iz; open = true;
 #pragma unroll
