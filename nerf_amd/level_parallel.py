@@ -42,7 +42,7 @@ def level_costs(cfg, world=8, binned_hashed=None):
 
         scatter  grows with the points of ALL ranks: 0.11 ms per 524 k points at the memory-side atomic rate whatever
                  the level's size, 0.09 on the big dense levels, 0.03 on the smallest dense levels (one LDS copy per
-                 workgroup) and 0.04-0.09, growing with the number of LDS chunks, on the chunked ones of the LDS-privatised kernel (per-rank step times of two
+                 workgroup) and 0.03-0.06, growing with the number of LDS chunks, on the chunked ones of the LDS-privatised kernel (per-rank step times of two
                  different assignments at world 8, tools/shard_step_emulate.py, solved for the levels);
         encode   (coarse + fine pass = 1.5 x the fine pass) likewise: 0.005 ms (L2-resident dense level) to 0.04 ms
                  (finest hashed level) per 524 k points;
@@ -63,7 +63,7 @@ def level_costs(cfg, world=8, binned_hashed=None):
             scatter = 0.112
             encode = 0.019 + 0.021 * (l - hashed[0]) / max(1, len(hashed) - 1)
         else:
-            scatter = 0.03 if floats <= 2 * 32768 else (0.04 + 0.05 * floats / (16 * 32768.0) if floats <= 16 * 32768 else 0.09)
+            scatter = 0.03 if floats <= 2 * 32768 else (0.03 + 0.03 * floats / (16 * 32768.0) if floats <= 16 * 32768 else 0.09)
             encode = 0.005 + 0.007 * min(1.0, cfg.entries[l] / float(1 << 24))
         adam = floats * 32 / 5.4e9
         if cfg.hashed[l] and binned_hashed and floats > 16 * 32768:
