@@ -12,6 +12,7 @@
 // roundings and the index parity depends on it.  fmaf is written out where a fused op is wanted.
 #pragma clang fp contract(off)
 
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -482,26 +483,31 @@ __global__ __launch_bounds__(256) void losses_kernel(const float* __restrict__ i
     __shared__ float s_s[kRaysPerBlock][kMaxS];
     __shared__ double s_part[kRaysPerBlock][4];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wv;
-    const bool live = ray < n_rays;
-    if (!live) ray = n_rays - 1;
     const int C = (S + kWave - 1) / kWave;
     const bool need_ws = weights != nullptr;
+    const float *w = s_w[wv], *s = s_s[wv];
+    double l_rgb = 0, l_mse = 0, l_dist = 0, l_depth = 0;
+    const double inv_n = 1.0 / (double)n_rays;
+    // A workgroup walks the rays with a grid-sized stride and adds its five totals once at the end: the fp64 atomics of
+    // all workgroups land on one 64-byte line and serialise there (4 ns each: 20 us with a workgroup per four rays).
+    for (int64_t base = (int64_t)blockIdx.x * kRaysPerBlock; base < n_rays; base += (int64_t)gridDim.x * kRaysPerBlock) {
+    int64_t ray = base + wv;
+    const bool live = ray < n_rays;
+    if (!live) ray = n_rays - 1;
+    __syncthreads();        // the previous round's readers of this wave's rows are done
     if (need_ws) {
         load_row(s_w[wv], weights + ray * S, S, lane);
         load_row(s_s[wv], zs + ray * S, S, lane);
     }
     __syncthreads();
-    const float *w = s_w[wv], *s = s_s[wv];
-    double l_rgb = 0, l_mse = 0, l_dist = 0, l_depth = 0;
-    const double inv_n = 1.0 / (double)n_rays;
+    double r_rgb = 0, r_mse = 0, r_dist = 0, r_depth = 0;
     // Huber(delta = 0.1), mean over N*3
     if (lane < 3) {
         float d = image[ray * 3 + lane] - gt[ray * 3 + lane];
         float ad = fabsf(d);
         const float hd = 0.1f;
-        l_rgb = ad <= hd ? 0.5 * (double)d * d : (double)hd * ((double)ad - 0.5 * hd);
-        l_mse = (double)d * d;
+        r_rgb = ad <= hd ? 0.5 * (double)d * d : (double)hd * ((double)ad - 0.5 * hd);
+        r_mse = (double)d * d;
         if (dimage && live) {
             float gr = ad <= hd ? d : (d > 0 ? hd : -hd);
             dimage[ray * 3 + lane] = grad_scale * gr * (float)(inv_n / 3.0);
@@ -525,10 +531,10 @@ __global__ __launch_bounds__(256) void losses_kernel(const float* __restrict__ i
                 gdw[c] = 0.f;
                 if (c < C && i < S) {
                     double wi = w[i], si = s[i];
-                    l_dist += 2.0 * wi * (si * pw - pws);
+                    r_dist += 2.0 * wi * (si * pw - pws);
                     double aw = tw - pw - wi, aws = tws - pws - wi * si;  // strictly after i
                     gdw[c] = (float)(2.0 * (si * pw - pws + aws - si * aw));
-                    l_depth += wi * (1.0 - si);
+                    r_depth += wi * (1.0 - si);
                     pw += wi;
                     pws += wi * si;
                 }
@@ -541,9 +547,9 @@ __global__ __launch_bounds__(256) void losses_kernel(const float* __restrict__ i
                 if (c < C && i < S) {
                     double acc = 0;
                     for (int j = 0; j < S; ++j) acc += (double)w[j] * fabs((double)s[i] - (double)s[j]);
-                    l_dist += (double)w[i] * acc;
+                    r_dist += (double)w[i] * acc;
                     gdw[c] = (float)(2.0 * acc);
-                    l_depth += (double)w[i] * (1.0 - (double)s[i]);
+                    r_depth += (double)w[i] * (1.0 - (double)s[i]);
                 }
             }
         }
@@ -557,12 +563,14 @@ __global__ __launch_bounds__(256) void losses_kernel(const float* __restrict__ i
             }
         }
     }
+    if (live) { l_rgb += r_rgb; l_mse += r_mse; l_dist += r_dist; l_depth += r_depth; }
+    }
     l_rgb = wave_sum(l_rgb); l_mse = wave_sum(l_mse); l_dist = wave_sum(l_dist); l_depth = wave_sum(l_depth);
     if (lane == 0) {
-        s_part[wv][0] = live ? l_rgb * inv_n / 3.0 : 0.0;
-        s_part[wv][1] = live ? l_dist * inv_n : 0.0;
-        s_part[wv][2] = live ? l_depth * inv_n / (double)S : 0.0;
-        s_part[wv][3] = live ? l_mse * inv_n / 3.0 : 0.0;
+        s_part[wv][0] = l_rgb * inv_n / 3.0;
+        s_part[wv][1] = l_dist * inv_n;
+        s_part[wv][2] = l_depth * inv_n / (double)S;
+        s_part[wv][3] = l_mse * inv_n / 3.0;
     }
     __syncthreads();
     if (threadIdx.x < 4) {
@@ -752,7 +760,9 @@ int nerf_losses(const float* image, const float* gt, const float* weights, const
     NERF_REQUIRE(check_ray_args(n_rays, n_samples) != 2, "n_samples must be in [1, 512]");
     NERF_REQUIRE(n_rays > 0, "need at least one ray");
     zero_doubles_kernel<<<1, 64, 0, S_(stream)>>>(sums, 5);
-    losses_kernel<<<(unsigned)ceil_div64(n_rays, kRaysPerBlock), 256, 0, S_(stream)>>>(
+    const int64_t loss_blocks = ceil_div64(n_rays, kRaysPerBlock);
+    static const int loss_cap = getenv("NERF_LOSS_BLOCKS") ? atoi(getenv("NERF_LOSS_BLOCKS")) : kNumCU;
+    losses_kernel<<<(unsigned)(loss_blocks < loss_cap ? loss_blocks : loss_cap), 256, 0, S_(stream)>>>(
         image, gt, weights, zlog_s, n_rays, n_samples, lam_dist, lam_depth, grad_scale, sorted, sums, dimage, dweights);
     return nerf_launch_status("nerf_losses");
 }
