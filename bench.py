@@ -341,7 +341,10 @@ def main():
             k['mfma_f32_frac'] = round(k['algorithmic_TFLOPs'] / MFMA_F32_PEAK_TFLOPS, 4)
         kernels.append(k)
     tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
-    pmc = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    # (the PMC passes were taken at N = 1 on the default table and batch: per-launch traffic of any other run is unmeasured)
+    default_workload = (args.rays == 4096 and args.table_log2 == 24 and args.levels == 20 and args.coarse == '64'
+                        and os.environ.get('NERF_TABLE_BINNED', '1') != '0')
+    pmc = json.load(open(tpath)) if os.path.exists(tpath) and world == 1 and default_workload else {}
 
     def roofline_of(k):
         # HBM bytes per launch from the committed PMC passes (tools/pmc_summary.py), same launch class
