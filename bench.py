@@ -96,7 +96,9 @@ def train_step(model, renderer, loader, opt, n_rays, it, world):
     lam_dist = 10 ** (it / 10000 * 3 - 5)            # trainer.py:160 with lambda 1e-5 -> 1e-2 over 10k iters
     loss, _ = helpers.fused_train_loss(rgb, rgb_gt, weights, zs, lam_dist, 1e-1)
     loss.backward()
+    opt.skip_flag = loss.nonfinite_flag        # Trainer.train_epoch's non-finite guard (device side, no sync)
     if world > 1:
+        parallel.all_reduce_sum_(opt.skip_flag)
         skip = [opt._table_param] if opt.table_reduced_by_pipeline() else []
         parallel.all_reduce_grads([p for g in opt.param_groups for p in g['params']], skip=skip)
         opt.grad_scale = 1.0 / world

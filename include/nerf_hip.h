@@ -48,14 +48,16 @@ typedef struct NerfGridCfg {
     uint64_t total_entries;
 } NerfGridCfg;
 
-/* Field network shape (nets.py:13-28 keyword arguments). */
+/* Field network shape (nets.py:13-28 keyword arguments).  The fused kernels cover exactly the shape of
+ * configs/config_base.yaml:78-100 plus the listed variations; any other value makes the fused entry points return
+ * NERF_EUNSUPPORTED (nerf_sigma_param_count / nerf_color_param_count are plain size formulas and accept any shape). */
 typedef struct NerfNetCfg {
     int32_t hidden_dim;    /* sigma_hidden_dim == color_hidden_dim, must be 64 */
-    int32_t sigma_layers;  /* sigma_num_layers, >= 2 */
+    int32_t sigma_layers;  /* sigma_num_layers, must be 2 (in -> 64 -> 16) */
     int32_t geo_feat_dim;  /* must be 15 (sigma net emits 16 rows) */
-    int32_t color_layers;  /* color_num_layers, >= 2 */
+    int32_t color_layers;  /* color_num_layers, must be 3 (in -> 64 -> 64 -> 3) */
     int32_t sh_degree;     /* encoding_dir_degree: 0, 2 or 4 */
-    int32_t latent_dim;    /* latent_embedding_dim, even, may be 0 */
+    int32_t latent_dim;    /* latent_embedding_dim, even, 0..48 */
 } NerfNetCfg;
 
 /* Where the sample points of a launch come from.
@@ -126,7 +128,9 @@ int nerf_mlp_bwd(const float* params, const int32_t* dims, int n_layers, const f
 /* NeRFNetwork.density (nets.py:148-164): normalise, hash-grid encode, sigma MLP, relu. */
 int nerf_density_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const float* table, const float* sigma_params,
                      const NerfPointSrc* src, float* sigma /*[M]*/, float* x_hashtable /*[M,L*F] nullable*/, void* stream);
-/* NeRFNetwork.forward (nets.py:109-146). rgb [M,3]; xyz [M,3] (uncontracted, mode 1 only) nullable. */
+/* NeRFNetwork.forward (nets.py:109-146). rgb [M,3]; xyz [M,3] (uncontracted, mode 1 only) nullable.
+ * An image index outside [0, n_images) (the reference's latent_emb[n] raises there, nets.py:132) is memory safe: the
+ * point reads a zero latent row, and nerf_field_bwd adds nothing to dlatent for it. */
 int nerf_field_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const float* table, const float* sigma_params,
                    const float* color_params, const float* latent_emb /*[n_images, latent_dim]*/, int64_t n_images,
                    const NerfPointSrc* src, float* sigma, float* rgb, float* x_hashtable /*nullable*/,
@@ -214,8 +218,9 @@ int nerf_composite_bwd(const float* sigma, const float* rgb, const float* zlog, 
                        const float* dweights, int64_t n_rays, int n_samples, float* dsigma, float* drgb, void* stream);
 
 /* ---- losses: helpers.py:21-32, trainer.py:153-169 ---- */
-/* sums[0..4] (double, zeroed by the call) receive loss_rgb, loss_dist, loss_depth, mse and
- * loss_rgb + lam_dist*loss_dist + lam_depth*loss_depth.
+/* sums[0..5] (SIX doubles, zeroed by the call) receive loss_rgb, loss_dist, loss_depth, mse,
+ * loss_rgb + lam_dist*loss_dist + lam_depth*loss_depth, and in sums[5] a non-finite flag: != 0 iff that total is
+ * NaN / Inf (the guard torch.cuda.amp.GradScaler provides at trainer.py:134-136; see nerf_adam_step_guarded).
  * dimage / dweights (nullable) receive grad_scale * d(loss_rgb + lam_dist*loss_dist + lam_depth*loss_depth).
  * sorted != 0 asserts zlog_s rows are non-decreasing (O(S) distortion form), else O(S^2). */
 int nerf_losses(const float* image, const float* gt, const float* weights, const float* zlog_s, int64_t n_rays,
@@ -226,6 +231,14 @@ int nerf_losses(const float* image, const float* gt, const float* weights, const
 /* step is the 1-based step count; when zero_grad != 0 the gradient is cleared in the same pass. */
 int nerf_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t count, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int64_t step, float grad_scale, int zero_grad, void* stream);
+
+/* nerf_adam_step with a device-side guard: skip_flag (nullable) points at a double written earlier on the stream
+ * (nerf_losses' sums[5]); when it is non-zero the parameters and moments are left untouched and only the gradient is
+ * cleared (zero_grad != 0) -- GradScaler.step's behaviour on a non-finite gradient (trainer.py:134-136), without a
+ * host synchronisation. */
+int nerf_adam_step_guarded(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t count, float lr,
+                           float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
+                           int zero_grad, const double* skip_flag, void* stream);
 
 /* ---- binned table update: tcnn HashGrid backward + torch.optim.Adam (train.py:84-88) on the hash table in one pass ----
  * The same result as nerf_hashgrid_scatter_levels into a zeroed gradient followed by nerf_adam_step over the listed
@@ -249,6 +262,12 @@ int nerf_table_bin_levels(const NerfGridCfg* grid, const NerfPointSrc* src, cons
 int nerf_table_update_binned(const NerfGridCfg* grid, const NerfLevelSet* levels, int64_t n_points, const void* workspace,
                              int64_t workspace_bytes, float* table, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
                              float beta2, float eps, float weight_decay, int64_t step, float grad_scale, void* stream);
+
+/* The same with the guard of nerf_adam_step_guarded: a non-zero *skip_flag drops the whole update. */
+int nerf_table_update_binned_guarded(const NerfGridCfg* grid, const NerfLevelSet* levels, int64_t n_points,
+                                     const void* workspace, int64_t workspace_bytes, float* table, float* exp_avg,
+                                     float* exp_avg_sq, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                     int64_t step, float grad_scale, const double* skip_flag, void* stream);
 
 /* ---- inference helpers: inference.py:97-105 ---- */
 int nerf_cum_weights_thresh(const float* weights, int64_t n_rays, int n_samples, float thresh, float* out, void* stream);

@@ -137,10 +137,16 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
         // (they are fetched again, from L2, right before the two places that stage them for the dW
         // products: holding 60 more registers across the whole tile costs scratch spills instead)
         const float* xrow = xh + p * LF + h * LHF;
-        const float* lrow = latent + q.n * s.lat + h * s.lat_half;
+        // (an image index outside the latent table: zero latent row, no latent gradient -- as in the forward)
+        const bool n_ok = (uint64_t)q.n < (uint64_t)s.n_img;
+        const float* lrow = latent + (n_ok ? q.n : 0) * s.lat + h * s.lat_half;
         float xf[XF], lat[24];
         load_features<XF>(xf, xrow, LHF, LF, h, vec);
         load_latent_half(lat, lrow, s.lat_half);
+        if (!n_ok) {
+#pragma unroll
+            for (int t = 0; t < 24; ++t) lat[t] = 0.f;
+        }
         // ------------------------- forward recompute -------------------------
         f32x16 a0, a1;
         {
@@ -197,6 +203,10 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
         __syncthreads();
         float lat2[24];
         load_latent_half(lat2, lrow, s.lat_half);      // lands under the dW MFMAs below
+        if (!n_ok) {
+#pragma unroll
+            for (int t = 0; t < 24; ++t) lat2[t] = 0.f;
+        }
         acc_c2 = dw_tile(acc_c2, SA, SB, wave >> 1, wave & 1, kHid, kHid, l31, h);
         {
             f32x16 t0, t1;
@@ -256,6 +266,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
             const int64_t n0 = __shfl(q.n, 0, kWave);
             const bool uniform = __all(q.n == n0);
             if (uniform) {
+                if ((uint64_t)n0 < (uint64_t)s.n_img) {
 #pragma unroll
                 for (int t = 8; t < 16; ++t) {
                     const float v = half_sum32(dG[t]);
@@ -268,7 +279,8 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
                     const int li = 16 + krow(t) + 4 * h;
                     if (l31 == 0 && li < s.lat) atomicAdd(dlatent + n0 * s.lat + li, v);
                 }
-            } else if (valid) {
+                }
+            } else if (valid && n_ok) {
 #pragma unroll
                 for (int t = 8; t < 16; ++t) {
                     const int li = krow(t) + 4 * h - 16;
@@ -380,7 +392,7 @@ extern "C" int nerf_field_bwd(const NerfGridCfg* grid, const NerfNetCfg* net, co
     NERF_REQUIRE(net->latent_dim == 0 || (latent_emb && dlatent && n_images > 0), "latent embedding missing");
     if (src->n_points == 0) return 0;
     const GridDev g = make_grid_dev(grid);
-    const NetLds s = make_net_lds(grid, net, true);
+    const NetLds s = make_net_lds(grid, net, true, n_images);
     NERF_UNSUPPORTED(s.in_sp > 64, "more than 64 hash-grid features");
     NERF_UNSUPPORTED(s.in_c > 96 || s.lat > 48, "colour-net input wider than 96 or latent wider than 48");
     NERF_UNSUPPORTED(net->latent_dim > 0 && !latent_emb, "latent table missing");

@@ -52,6 +52,7 @@ struct NetLds {
     int in_c;    // 15 + sh_dim + latent
     int sh_dim, sh_half, lat, lat_half;
     int total;   // floats of LDS used by the weights
+    int64_t n_img;  // rows of latent_emb: an image index outside [0, n_img) reads a zero latent row and writes no gradient
 };
 
 static inline GridDev make_grid_dev(const NerfGridCfg* g) {
@@ -69,7 +70,7 @@ static inline GridDev make_grid_dev(const NerfGridCfg* g) {
     return d;
 }
 
-static inline NetLds make_net_lds(const NerfGridCfg* g, const NerfNetCfg* n, bool with_color) {
+static inline NetLds make_net_lds(const NerfGridCfg* g, const NerfNetCfg* n, bool with_color, int64_t n_images = 0) {
     NetLds s = {};
     s.in_s = g->n_levels * g->n_features;
     s.in_sp = 2 * ((g->n_levels + 1) / 2) * g->n_features;
@@ -79,6 +80,7 @@ static inline NetLds make_net_lds(const NerfGridCfg* g, const NerfNetCfg* n, boo
     s.lat_half = s.lat / 2;
     s.in_c = n->geo_feat_dim + s.sh_dim + s.lat;
     s.total = with_color ? kNetLdsFull : kNetLdsSigma;
+    s.n_img = n_images;
     return s;
 }
 

@@ -42,8 +42,15 @@ __global__ __launch_bounds__(512) void field_fwd_kernel(GridDev g, NetLds s, con
         if (!FEATS || COLOR) q = fetch_point(src, p, COLOR);
         float lat[24];   // this lane's half of the latent row, fetched under the hash-grid gathers
         if (COLOR) {
-            const float* lrow = latent + q.n * s.lat + h * s.lat_half;
+            // (the reference's latent_emb[n] raises for an index outside the table, nets.py:132: here such a point reads
+            // a zero latent row instead of foreign memory)
+            const bool n_ok = (uint64_t)q.n < (uint64_t)s.n_img;
+            const float* lrow = latent + (n_ok ? q.n : 0) * s.lat + h * s.lat_half;
             load_latent_half(lat, lrow, s.lat_half);
+            if (!n_ok) {
+#pragma unroll
+                for (int t = 0; t < 24; ++t) lat[t] = 0.f;
+            }
         }
 
         // ---- sigma layer 1: encode a level, feed its F features as the next F k-steps ----
@@ -446,10 +453,10 @@ static int resident_blocks_per_cu(K kern, int threads, int lds_bytes) {
 
 template <bool COLOR, bool FEATS>
 static int launch_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const float* table, const float* sw, const float* cw,
-                      const float* latent, const NerfPointSrc* src, float* sigma, float* rgb, float* xh, float* xyz,
-                      const float* xh_in, void* stream) {
+                      const float* latent, int64_t n_images, const NerfPointSrc* src, float* sigma, float* rgb, float* xh,
+                      float* xyz, const float* xh_in, void* stream) {
     const GridDev g = make_grid_dev(grid);
-    const NetLds s = make_net_lds(grid, net, COLOR);
+    const NetLds s = make_net_lds(grid, net, COLOR, n_images);
     int lds_bytes = s.total * (int)sizeof(float);
     // feature rows staged per wave (see the kernel): one 512-thread workgroup per CU instead of two of 256 threads, so
     // that the weights are held once and 8 x [32][L*F] floats fit beside them
@@ -491,8 +498,8 @@ int nerf_density_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const float
     if (rc) return rc;
     NERF_REQUIRE(table && sigma_params && sigma, "null pointer");
     if (src->n_points == 0) return 0;
-    return launch_fwd<false, false>(grid, net, table, sigma_params, nullptr, nullptr, src, sigma, nullptr, x_hashtable, nullptr,
-                                    nullptr, stream);
+    return launch_fwd<false, false>(grid, net, table, sigma_params, nullptr, nullptr, 0, src, sigma, nullptr, x_hashtable,
+                                    nullptr, nullptr, stream);
 }
 
 int nerf_field_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const float* table, const float* sigma_params,
@@ -505,8 +512,8 @@ int nerf_field_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const float* 
     NERF_REQUIRE(table && sigma_params && color_params && sigma && rgb, "null pointer");
     NERF_REQUIRE(net->latent_dim == 0 || (latent_emb && n_images > 0), "latent embedding missing");
     if (src->n_points == 0) return 0;
-    return launch_fwd<true, false>(grid, net, table, sigma_params, color_params, latent_emb, src, sigma, rgb, x_hashtable, xyz,
-                                   nullptr, stream);
+    return launch_fwd<true, false>(grid, net, table, sigma_params, color_params, latent_emb, n_images, src, sigma, rgb,
+                                   x_hashtable, xyz, nullptr, stream);
 }
 
 int nerf_hashgrid_fwd(const NerfGridCfg* grid, const float* table, const float* x01, int64_t n_points, float* out,
@@ -688,8 +695,8 @@ extern "C" int nerf_density_from_features(const NerfGridCfg* grid, const NerfNet
     NerfPointSrc src = {};
     src.n_points = n_points;
     src.outer_bound = 1.f;
-    return launch_fwd<false, true>(grid, net, nullptr, sigma_params, nullptr, nullptr, &src, sigma, nullptr, nullptr, nullptr,
-                                   x_hashtable, stream);
+    return launch_fwd<false, true>(grid, net, nullptr, sigma_params, nullptr, nullptr, 0, &src, sigma, nullptr, nullptr,
+                                   nullptr, x_hashtable, stream);
 }
 
 extern "C" int nerf_field_from_features(const NerfGridCfg* grid, const NerfNetCfg* net, const float* sigma_params,
@@ -703,8 +710,8 @@ extern "C" int nerf_field_from_features(const NerfGridCfg* grid, const NerfNetCf
     NERF_REQUIRE(sigma_params && color_params && x_hashtable && sigma && rgb, "null pointer");
     NERF_REQUIRE(net->latent_dim == 0 || (latent_emb && n_images > 0), "latent embedding missing");
     if (src->n_points == 0) return 0;
-    return launch_fwd<true, true>(grid, net, nullptr, sigma_params, color_params, latent_emb, src, sigma, rgb, nullptr, xyz,
-                                  x_hashtable, stream);
+    return launch_fwd<true, true>(grid, net, nullptr, sigma_params, color_params, latent_emb, n_images, src, sigma, rgb,
+                                  nullptr, xyz, x_hashtable, stream);
 }
 
 namespace {

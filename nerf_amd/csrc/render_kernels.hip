@@ -580,6 +580,9 @@ __global__ __launch_bounds__(256) void losses_kernel(const float* __restrict__ i
         double v = 0;
         for (int k = 0; k < 4; ++k) v += s_part[k][0] + (double)lam_dist * s_part[k][1] + (double)lam_depth * s_part[k][2];
         atomicAdd(&sums[4], v);
+        // non-finite guard (the role GradScaler plays at trainer.py:134-136): a NaN / Inf anywhere in image, weights or
+        // zlog_s reaches this workgroup's total; the guarded optimizer entry points drop the step when sums[5] != 0
+        if (!(fabs(v) <= 1.7976931348623157e308)) atomicAdd(&sums[5], 1.0);
     }
 }
 
@@ -759,7 +762,7 @@ int nerf_losses(const float* image, const float* gt, const float* weights, const
     NERF_REQUIRE((weights == nullptr) == (zlog_s == nullptr), "weights and zlog_s go together");
     NERF_REQUIRE(check_ray_args(n_rays, n_samples) != 2, "n_samples must be in [1, 512]");
     NERF_REQUIRE(n_rays > 0, "need at least one ray");
-    zero_doubles_kernel<<<1, 64, 0, S_(stream)>>>(sums, 5);
+    zero_doubles_kernel<<<1, 64, 0, S_(stream)>>>(sums, 6);
     const int64_t loss_blocks = ceil_div64(n_rays, kRaysPerBlock);
     static const int loss_cap = getenv("NERF_LOSS_BLOCKS") ? atoi(getenv("NERF_LOSS_BLOCKS")) : kNumCU;
     losses_kernel<<<(unsigned)(loss_blocks < loss_cap ? loss_blocks : loss_cap), 256, 0, S_(stream)>>>(

@@ -306,8 +306,10 @@ __global__ __launch_bounds__(kUpdThreads) void table_update_kernel(GridDev g, Bi
                                                                    const uint16_t* __restrict__ item_idx,
                                                                    const float* __restrict__ item_val, int64_t n_items_level,
                                                                    float* __restrict__ p, float* __restrict__ m,
-                                                                   float* __restrict__ v, AdamK k) {
+                                                                   float* __restrict__ v, AdamK k,
+                                                                   const double* __restrict__ skip) {
     extern __shared__ __attribute__((aligned(16))) float acc[];
+    if (skip && *skip != 0.0) return;       // non-finite loss this step (nerf_losses sums[5]): the step is dropped
     const uint32_t part = blockIdx.x;
     int slot = 0;
     while (slot + 1 < plan.count && part >= plan.part_base[slot + 1]) ++slot;
@@ -489,10 +491,11 @@ extern "C" int nerf_table_bin_levels(const NerfGridCfg* grid, const NerfPointSrc
     return nerf_launch_status("nerf_table_bin_levels");
 }
 
-extern "C" int nerf_table_update_binned(const NerfGridCfg* grid, const NerfLevelSet* levels, int64_t n_points,
-                                        const void* workspace, int64_t workspace_bytes, float* table, float* exp_avg,
-                                        float* exp_avg_sq, float lr, float beta1, float beta2, float eps, float weight_decay,
-                                        int64_t step, float grad_scale, void* stream) {
+extern "C" int nerf_table_update_binned_guarded(const NerfGridCfg* grid, const NerfLevelSet* levels, int64_t n_points,
+                                                const void* workspace, int64_t workspace_bytes, float* table, float* exp_avg,
+                                                float* exp_avg_sq, float lr, float beta1, float beta2, float eps,
+                                                float weight_decay, int64_t step, float grad_scale, const double* skip_flag,
+                                                void* stream) {
     NERF_REQUIRE(grid && workspace && table && exp_avg && exp_avg_sq, "null pointer");
     NERF_REQUIRE(step >= 1, "bad step");
     NERF_REQUIRE((((uintptr_t)table | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq | (uintptr_t)workspace) & 15) == 0,
@@ -517,7 +520,7 @@ extern "C" int nerf_table_update_binned(const NerfGridCfg* grid, const NerfLevel
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);  \
         if (e != hipSuccess) { nerf_set_error("nerf_table_update_binned: LDS attribute: %s", hipGetErrorString(e)); return (int)e; } \
         kern<<<nb, kUpdThreads, lds_bytes, st>>>(g, plan, bin_start, item_idx, item_val, 8 * n_points, table, exp_avg,   \
-                                                 exp_avg_sq, k); \
+                                                 exp_avg_sq, k, skip_flag); \
     } while (0)
     switch (grid->n_features) {
         case 1: UPDATE(1); break;
@@ -526,4 +529,12 @@ extern "C" int nerf_table_update_binned(const NerfGridCfg* grid, const NerfLevel
     }
 #undef UPDATE
     return nerf_launch_status("nerf_table_update_binned");
+}
+
+extern "C" int nerf_table_update_binned(const NerfGridCfg* grid, const NerfLevelSet* levels, int64_t n_points,
+                                        const void* workspace, int64_t workspace_bytes, float* table, float* exp_avg,
+                                        float* exp_avg_sq, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                        int64_t step, float grad_scale, void* stream) {
+    return nerf_table_update_binned_guarded(grid, levels, n_points, workspace, workspace_bytes, table, exp_avg, exp_avg_sq, lr,
+                                            beta1, beta2, eps, weight_decay, step, grad_scale, nullptr, stream);
 }

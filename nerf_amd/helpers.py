@@ -19,7 +19,7 @@ class _LossFn(torch.autograd.Function):
         w = f32(weights) if use_w else None
         s = f32(zlog_s) if use_w else None
         S = w.shape[1] if use_w else 1
-        sums = torch.empty(5, device=img.device, dtype=torch.float64)
+        sums = torch.empty(6, device=img.device, dtype=torch.float64)
         dimage = torch.empty_like(img)
         dweights = torch.empty_like(w) if use_w else None
         check(lib().nerf_losses(ptr(img), ptr(g), ptr(w), ptr(s), N, S, lam_dist, lam_depth, 1.0, 1 if sorted_s else 0,
@@ -30,12 +30,13 @@ class _LossFn(torch.autograd.Function):
         both = sums.to(torch.float32)
         parts = both[:4]
         out = both[{'rgb': 0, 'dist': 1, 'depth': 2, 'mse': 3, 'total': 4}[want]]
-        ctx.mark_non_differentiable(parts)
+        flag = sums[5:6]            # fp64, != 0 iff the total loss is NaN / Inf (nerf_losses)
+        ctx.mark_non_differentiable(parts, flag)
         ctx.set_materialize_grads(False)
-        return out, parts
+        return out, parts, flag
 
     @staticmethod
-    def backward(ctx, dout, _dparts):
+    def backward(ctx, dout, _dparts, _dflag):
         dimage, dweights = ctx.saved_tensors
         if dout is None:
             return None, None, None, None, None, None, None, None
@@ -45,15 +46,20 @@ class _LossFn(torch.autograd.Function):
 
 
 def fused_train_loss(image, gt, weights, zlog_s, lam_dist, lam_depth, sorted_s=True):
-    """Returns (loss, parts[4] = loss_rgb, loss_dist, loss_depth, mse); one kernel, fwd + grads."""
-    return _LossFn.apply(image, gt, weights, zlog_s, float(lam_dist), float(lam_depth), sorted_s, 'total')
+    """Returns (loss, parts[4] = loss_rgb, loss_dist, loss_depth, mse); one kernel, fwd + grads.
+    ``loss.nonfinite_flag`` is a one-element fp64 device tensor, != 0 iff the loss is NaN / Inf: hand it to
+    ``FusedAdam.skip_flag`` and the step is dropped on the device, without a host sync (the role GradScaler plays in
+    the reference, trainer.py:134-136)."""
+    loss, parts, flag = _LossFn.apply(image, gt, weights, zlog_s, float(lam_dist), float(lam_depth), sorted_s, 'total')
+    loss.nonfinite_flag = flag
+    return loss, parts
 
 
 ## Losses and Metrics
 def psnr(rgb_, rgb):
     """helpers.py:11-13 (returns a Python float, like the reference)."""
     with torch.no_grad():
-        _, parts = _LossFn.apply(rgb_, rgb, None, None, 0.0, 0.0, True, 'rgb')
+        _, parts, _ = _LossFn.apply(rgb_, rgb, None, None, 0.0, 0.0, True, 'rgb')
     return -10.0 * m.log10(float(parts[3]))
 
 
@@ -69,11 +75,11 @@ def criterion_dist(weights, z_vals, assume_sorted=True):
     ``render`` returns) selects the O(S) form; pass False for arbitrary sample order."""
     N = weights.shape[0]
     dummy = torch.zeros(N, 3, device=weights.device)
-    out, _ = _LossFn.apply(dummy, dummy, weights, z_vals.detach(), 1.0, 0.0, assume_sorted, 'dist')
+    out, _, _ = _LossFn.apply(dummy, dummy, weights, z_vals.detach(), 1.0, 0.0, assume_sorted, 'dist')
     return out
 
 
 def criterion_rgb(rgb_, rgb):
     """helpers.py:29-32: Huber loss, delta = 0.1, mean reduction."""
-    out, _ = _LossFn.apply(rgb_, rgb, None, None, 0.0, 0.0, True, 'rgb')
+    out, _, _ = _LossFn.apply(rgb_, rgb, None, None, 0.0, 0.0, True, 'rgb')
     return out

@@ -188,6 +188,7 @@ class _FieldFn(torch.autograd.Function):
     def backward(ctx, dsigma, drgb, _dxh, _dxyz):
         table, sigma_w, color_w, latent, xh = ctx.saved_tensors
         net = ctx.net
+        net.backward_count += 1
         src = make_point_src(**ctx.src_kwargs)
         dev = table.device
         if dsigma is None:
@@ -321,6 +322,7 @@ class _ShardedFieldFn(torch.autograd.Function):
     def backward(ctx, dsigma, drgb, _dxh, _dxyz):
         table, sigma_w, color_w, latent, xh = ctx.saved_tensors
         net, sh = ctx.net, ctx.net.level_sharding
+        net.backward_count += 1
         src = make_point_src(**ctx.src_kwargs)
         dev = table.device
         if dsigma is None:
@@ -359,6 +361,15 @@ class NeRFNetwork(nn.Module):
             raise ValueError('encoding_dir_precision must be float16 or float32')   # nets.py:67-72
         if encoding_dir_degree != 0 and encoding_dir_encoding != 'SphericalHarmonics':
             raise NotImplementedError('only the SphericalHarmonics direction encoding is implemented')
+        # the fused kernels cover exactly this shape (csrc/field_fwd.hip nerf_check_cfg): reject anything else here,
+        # before the 1.6 GB table is allocated, instead of at the first forward
+        if (sigma_hidden_dim != 64 or color_hidden_dim != 64 or sigma_num_layers != 2 or color_num_layers != 3
+                or geo_feat_dim != 15):
+            raise NotImplementedError('fused kernels need sigma/color hidden_dim 64, sigma_num_layers 2, color_num_layers 3, '
+                                      'geo_feat_dim 15 (got %s/%s, %s, %s, %s)' % (sigma_hidden_dim, color_hidden_dim,
+                                                                                   sigma_num_layers, color_num_layers, geo_feat_dim))
+        if encoding_dir_degree not in (0, 2, 4) or latent_embedding_dim % 2 or not 0 <= latent_embedding_dim <= 48:
+            raise NotImplementedError('fused kernels need SH degree 0, 2 or 4 and an even latent_embedding_dim <= 48')
         # precision: the reference's fp16 switch only changes tcnn's storage type; this build computes in
         # fp32 (the CPU/fp32 semantics are the parity spec), so both values run fp32.
         self.encoding_precision = torch.float32
@@ -386,6 +397,7 @@ class NeRFNetwork(nn.Module):
         self.net_cfg = NerfNetCfg(sigma_hidden_dim, sigma_num_layers, geo_feat_dim, color_num_layers, encoding_dir_degree,
                                   latent_embedding_dim)
         self.direct_grads = False
+        self.backward_count = 0         # backward passes that reached the field (FusedAdam.zero_grad keys its fast path on it)
         self.table_pipeline = None
         self.level_sharding = None      # level_parallel.LevelSharding under multi-GPU training
         self._local_table = 0           # >0: inside `with model.local_table()` (replicated-table kernels)

@@ -152,7 +152,13 @@ class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.grad_scale = 1.0
-        self._grads_cleared = False
+        self._cleared_at = None       # model.backward_count at the end of the last step() (attached models only)
+        # Non-finite guard: a one-element fp64 device tensor (helpers.fused_train_loss -> loss.nonfinite_flag); when it is
+        # non-zero the NEXT step() leaves parameters and moments untouched and only clears the gradients -- decided on
+        # the device, no host sync (GradScaler's role at trainer.py:134-136).  Consumed by one step().
+        self.skip_flag = None
+        self.skipped_steps = 0        # steps found dropped so far (read back lazily, see _collect_flags)
+        self._flag_reads = []         # (event, pinned host copy) of the flags of earlier steps
         self._table_param = None
         self._pipeline = None
         self._sharding = None
@@ -189,18 +195,51 @@ class FusedAdam(torch.optim.Optimizer):
         return self
 
     def zero_grad(self, set_to_none=False):
-        if self._grads_cleared:       # the last step() already cleared them in its own pass
-            self._grads_cleared = False
-            return
+        model = getattr(self, '_model', None)
+        if model is not None and self._cleared_at is not None and self._cleared_at == model.backward_count:
+            return      # no backward has reached the model since the last step(), which cleared every gradient in its own pass
+        self._cleared_at = None
         if self._pipeline is not None:
-            self._pipeline.drop_binned()      # binned corner updates of a backward that is being discarded
+            # a backward is being discarded (e.g. a non-finite loss): its binned corner updates and the pending
+            # per-level pipeline state go with it
+            pipe = self._pipeline
+            pipe.drop_binned()
+            if pipe.scatter_stream is not None:     # scatters of the discarded pass may still be running beside us
+                torch.cuda.current_stream().wait_stream(pipe.scatter_stream)
+            for w in pipe.works.values():
+                if w is not None:
+                    w.wait()
+            pipe.works = {}
+            pipe.pending = False
         for group in self.param_groups:
             for p in group['params']:
                 if p.grad is not None:
                     p.grad.zero_()
 
+    def _collect_flags(self, wait=False):
+        """Flags of earlier steps whose host copy has arrived: a dropped step must not count in Adam's bias correction
+        (GradScaler does not call optimizer.step at all), so the step counters are taken back -- a few steps late, which
+        only touches the bias-correction factor of those few steps, but without ever blocking the host."""
+        keep = []
+        for ev, host in self._flag_reads:
+            if wait:
+                ev.synchronize()
+            if ev.query():
+                if float(host[0]) != 0.0:
+                    self.skipped_steps += 1
+                    for st in self.state.values():
+                        if st and st.get('step', 0) > 0:
+                            st['step'] -= 1
+            else:
+                keep.append((ev, host))
+        self._flag_reads = keep
+
     @torch.no_grad()
     def step(self, closure=None):
+        flag = self.skip_flag
+        self._skip_ptr = ptr(flag) if flag is not None else None
+        if self._flag_reads:
+            self._collect_flags()
         for group in self.param_groups:
             b1, b2 = group['betas']
             for p in group['params']:
@@ -237,11 +276,20 @@ class FusedAdam(torch.optim.Optimizer):
                         self._adam(flat_p[a:b], flat_g[a:b], flat_m[a:b], flat_v[a:b], group, b1, b2, st['step'])
                     continue
                 self._adam(p, p.grad, st['exp_avg'], st['exp_avg_sq'], group, b1, b2, st['step'])
-        self._grads_cleared = True
+        model = getattr(self, '_model', None)
+        self._cleared_at = model.backward_count if model is not None else None
+        if flag is not None:
+            host = torch.empty(1, dtype=torch.float64, pin_memory=True)
+            host.copy_(flag, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._flag_reads.append((ev, host))
+            self.skip_flag = None
 
     def _adam(self, p, g, m, v, group, b1, b2, step):
-        check(lib().nerf_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), group['lr'], b1, b2, group['eps'],
-                                   group['weight_decay'], step, self.grad_scale, 1, stream()), 'nerf_adam_step')
+        check(lib().nerf_adam_step_guarded(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), group['lr'], b1, b2, group['eps'],
+                                           group['weight_decay'], step, self.grad_scale, 1, getattr(self, '_skip_ptr', None),
+                                           stream()), 'nerf_adam_step')
 
     @torch.no_grad()
     def sync_sharded_state(self):
@@ -265,9 +313,10 @@ class FusedAdam(torch.optim.Optimizer):
         cfg = self._model.encoder.cfg
         if pipe.binned_pending is not None:
             n_points, nbytes = pipe.binned_pending
-            check(lib().nerf_table_update_binned(C.byref(cfg), C.byref(pipe.binned_set), n_points, ptr(pipe.binned_ws), nbytes,
-                                                 ptr(p), ptr(st['exp_avg']), ptr(st['exp_avg_sq']), group['lr'], b1, b2,
-                                                 group['eps'], group['weight_decay'], st['step'], self.grad_scale, stream()),
+            check(lib().nerf_table_update_binned_guarded(C.byref(cfg), C.byref(pipe.binned_set), n_points, ptr(pipe.binned_ws),
+                                                         nbytes, ptr(p), ptr(st['exp_avg']), ptr(st['exp_avg_sq']), group['lr'],
+                                                         b1, b2, group['eps'], group['weight_decay'], st['step'],
+                                                         self.grad_scale, getattr(self, '_skip_ptr', None), stream()),
                   'nerf_table_update_binned')
         else:
             # gradient accumulation (several backward passes) or no backward at all: the gradients of these levels

@@ -170,6 +170,8 @@ def all_to_all_blocks(recv_blocks, send_blocks, async_op=False):
     """send_blocks[r] -> rank r, recv_blocks[r] <- rank r (flat, contiguous views; sizes must match pairwise).
     The caller's OWN block is not transferred -- callers fill / consume it locally while the exchange is in flight.
     Returns a work handle when async_op and the backend is asynchronous (RCCL), else None."""
+    if not dist.is_initialized():      # no process group: the only block is the caller's own, which it fills locally
+        return None
     me, world = rank(), world_size()
     if dist.get_backend() == 'gloo':       # no list all-to-all in gloo: one flat exchange of host tensors
         ins = [b.reshape(-1).cpu() for i, b in enumerate(send_blocks) if i != me]

@@ -98,6 +98,10 @@ class Trainer(object):
                         'scheduler': self.scheduler.state_dict() if self.scheduler is not None else None}, path)
 
     def load_checkpoint(self, path, map_location='cuda'):
+        """Resume from a file written by save_checkpoint.  NOT a loader for .pth files trained by the reference: the keys
+        match (encoder.params, sigma_net.params, color_net.params, latent_emb) but tinycudann's FullyFusedMLP stores its
+        layers padded to multiples of 16 inputs / outputs, so load_state_dict reports a size mismatch for them; the
+        padded layout is unpinned (tinycudann is absent, the reference ships no checkpoint) and is not converted."""
         ck = torch.load(path, map_location=map_location, weights_only=True)
         self.model.load_state_dict(ck['model'])
         self.optimizer.load_state_dict(ck['optimizer'])
@@ -114,6 +118,11 @@ class Trainer(object):
             loss = self.train_step()
             loss.backward()
             world = parallel.world_size()
+            flag = getattr(loss, 'nonfinite_flag', None)
+            if flag is not None and hasattr(self.optimizer, 'skip_flag'):
+                if world > 1:           # every rank must take the same decision
+                    parallel.all_reduce_sum_(flag)
+                self.optimizer.skip_flag = flag      # a non-finite loss drops this step on the device (no host sync)
             if world > 1:
                 skip = [self.optimizer._table_param] if getattr(self.optimizer, 'table_reduced_by_pipeline', lambda: False)() else []
                 parallel.all_reduce_grads([p for g in self.optimizer.param_groups for p in g['params']], skip=skip)
