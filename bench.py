@@ -106,18 +106,14 @@ def train_step(model, renderer, loader, opt, n_rays, it, world):
     return loss
 
 
-def cpu_baseline(n_rays=1024, steps=2, threads=16):
-    """The CPU oracle on a bounded sample: `steps` train steps of `n_rays` rays, config_base network."""
+def _cpu_steps(ora, R, opt, n_rays, steps, warm, seed):
+    """`warm` + `steps` oracle train steps of `n_rays` rays; per timed step (render fwd, loss + backward, Adam) seconds."""
     from oracle import ref_cpu
     from nerf_amd.loaders.procedural import sphere_cameras
-    torch.set_num_threads(threads)
-    ora = ref_cpu.OracleNetwork(N_IMAGES, seed=0, **NET)
-    R = ref_cpu.OracleRenderer(ora, INNER, OUTER, Z_BOUNDS, STEPS, SF, ALPHA)
-    opt = ref_cpu.make_optimizer(ora)
     K_all, E_all = sphere_cameras(N_IMAGES, 0)
-    g = torch.Generator().manual_seed(0)
-    times = []
-    for it in range(steps + 1):
+    g = torch.Generator().manual_seed(seed)
+    rows = []
+    for it in range(warm + steps):
         n = torch.randint(0, N_IMAGES, (n_rays,), generator=g)
         h = torch.randint(0, H, (n_rays,), generator=g)
         w = torch.randint(0, W, (n_rays,), generator=g)
@@ -125,25 +121,53 @@ def cpu_baseline(n_rays=1024, steps=2, threads=16):
         t0 = time.perf_counter()
         opt.zero_grad()
         img, wts, zs, _ = R.render(n, h, w, K_all[n], E_all[n], bg)
+        t1 = time.perf_counter()
         loss, _ = ref_cpu.train_loss(img, gt, wts, zs, it, 10000, 1e-5, 1e-2, 1e-1, 1e-1)
         loss.backward()
+        t2 = time.perf_counter()
         opt.step()
-        times.append(time.perf_counter() - t0)
-    t = sorted(times[1:])[len(times[1:]) // 2]
-    with torch.no_grad():           # forward-only render of the same rays (the inference half of the metric)
+        t3 = time.perf_counter()
+        if it >= warm:
+            rows.append((t1 - t0, t2 - t1, t3 - t2))
+    with torch.no_grad():           # forward-only render of the last batch (the inference half of the metric)
         t0 = time.perf_counter()
         R.render(n, h, w, K_all[n], E_all[n], bg)
         t_render = time.perf_counter() - t0
+    med = lambda xs: sorted(xs)[len(xs) // 2]
+    tot = med([sum(r) for r in rows])
+    return {'seconds_per_step': tot, 'render_fwd_s': med([r[0] for r in rows]), 'loss_backward_s': med([r[1] for r in rows]),
+            'adam_s': med([r[2] for r in rows]), 'rays_per_s': n_rays / tot, 'render_only_rays_per_s': n_rays / t_render}
+
+
+def cpu_baseline(n_rays=4096, steps=3, threads=16):
+    """The CPU oracle (oracle/ref_cpu.py, fp32 torch CPU; a port -- the reference's network needs the CUDA-only tinycudann)
+    on a bounded sample of the SAME workload: `steps` timed train steps (after one warm-up) of `n_rays` rays of the
+    metric configuration, config_base network with the 2^24 table and torch.optim.Adam over all of it; then, for
+    orientation, SURVEY's C1 case (1024 rays, 480 coarse + 128 fine samples).  Phases are reported separately: the dense
+    Adam pass over 400 M parameters does not shrink with the batch."""
+    from oracle import ref_cpu
+    threads = min(threads, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    ora = ref_cpu.OracleNetwork(N_IMAGES, seed=0, **NET)
+    opt = ref_cpu.make_optimizer(ora)
+    R = ref_cpu.OracleRenderer(ora, INNER, OUTER, Z_BOUNDS, STEPS, SF, ALPHA)
+    main = _cpu_steps(ora, R, opt, n_rays, steps, 1, 0)
+    R1 = ref_cpu.OracleRenderer(ora, INNER, OUTER, [0.1, 1, 10, 100, 1000], [256, 128, 64, 32], SF, ALPHA)
+    c1 = _cpu_steps(ora, R1, opt, 1024, 2, 1, 1)
     cpu_model = ''
     try:
         with open('/proc/cpuinfo') as f:
             cpu_model = next((l.split(':', 1)[1].strip() for l in f if l.startswith('model name')), '')
     except OSError:
         pass
-    return {'value': n_rays / t, 'unit': 'rays/s', 'cores': threads, 'kind': 'port', 'render_rays_per_s': n_rays / t_render,
-            'cpu_model': cpu_model, 'host_cpus': os.cpu_count(),
-            'sample': '%d train steps of %d rays (1 warm-up), oracle/ref_cpu.py fp32 torch CPU, same network/renderer config'
-                      % (steps, n_rays), 'seconds_per_step': t}
+    return {'value': main['rays_per_s'], 'unit': 'rays/s', 'cores': threads, 'kind': 'port',
+            'render_rays_per_s': main['render_only_rays_per_s'], 'cpu_model': cpu_model, 'host_cpus': os.cpu_count(),
+            'sample': '%d timed train steps of %d rays (1 warm-up, median), %d coarse + %d fine samples, oracle/ref_cpu.py fp32 '
+                      'torch CPU, same network / renderer / Adam configuration' % (steps, n_rays, sum(STEPS), SF),
+            'seconds_per_step': main['seconds_per_step'],
+            'phases_s': {k: main[k] for k in ('render_fwd_s', 'loss_backward_s', 'adam_s')},
+            'c1_1024_rays_480_coarse': {k: c1[k] for k in ('rays_per_s', 'render_only_rays_per_s', 'seconds_per_step',
+                                                           'render_fwd_s', 'loss_backward_s', 'adam_s')}}
 
 
 def _beat():
@@ -341,12 +365,24 @@ def main():
         if fl:
             k['algorithmic_TFLOPs'] = round(fl / (per_step_ms * 1e-3) / 1e12, 2)
             k['mfma_f32_frac'] = round(k['algorithmic_TFLOPs'] / MFMA_F32_PEAK_TFLOPS, 4)
+            k['mfma_busy_counter'] = None       # filled below from profiles/mfma.json when the run matches it
         kernels.append(k)
     tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
     # (the PMC passes were taken at N = 1 on the default table and batch: per-launch traffic of any other run is unmeasured)
     default_workload = (args.rays == 4096 and args.table_log2 == 24 and args.levels == 20 and args.coarse == '64'
                         and os.environ.get('NERF_TABLE_BINNED', '1') != '0')
     pmc = json.load(open(tpath)) if os.path.exists(tpath) and world == 1 and default_workload else {}
+
+    mpath = os.path.join(ROOT, 'profiles', 'mfma.json')
+    mfma = json.load(open(mpath)) if os.path.exists(mpath) and world == 1 and default_workload else {}
+
+    def mfma_counter(name):
+        """Counter-based MFMA utilisation of the kernel behind an entry point, from the committed
+        rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES / GRBM_GUI_ACTIVE pass (tools/mfma_summary.py)."""
+        rec = mfma.get('per_kernel', {}).get(name.split('[')[0])
+        if not rec:
+            return None
+        return dict(rec, source='committed PMC pass, not this run: profiles/mfma.json (build %s)' % mfma.get('build', '?'))
 
     def roofline_of(k):
         # HBM bytes per launch from the committed PMC passes (tools/pmc_summary.py), same launch class
@@ -355,14 +391,22 @@ def main():
             # the MLP backward is bound by the matrix cores, not by its 336 B per point
             return {'kernel': k['name'], 'bound': 'mfma', 'achieved': k.get('algorithmic_TFLOPs'),
                     'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': k.get('mfma_f32_frac'),
-                    'traffic': rec['hbm_bytes'] if rec else None, 'avg_launch_ms': k['avg_launch_ms'],
+                    'traffic': rec['hbm_bytes'] if rec else None,
+                    'traffic_source': ('committed PMC passes, not this run: profiles/traffic.json (build %s)' % pmc.get('build', '?')) if rec else None,
+                    'mfma_busy': mfma_counter(k['name']), 'avg_launch_ms': k['avg_launch_ms'],
                     'launches_per_step': k['launches_per_step'],
                     'algorithmic_flops_per_launch': algorithmic_flops('nerf_field_bwd', args.rays, Sc=sum(STEPS))
                     / max(1.0, k['launches_per_step'])}
         return {'kernel': k['name'], 'bound': 'hbm', 'achieved': k.get('algorithmic_GBps'), 'peak': HBM_PEAK_GBS,
                 'unit': 'GB/s', 'frac': k.get('hbm_frac'), 'traffic': rec['hbm_bytes'] if rec else None,
+                'traffic_source': (('committed PMC passes, not this run: profiles/traffic.json (build %s; rocprofv3 --pmc FETCH_SIZE '
+                                    '/ WRITE_SIZE, per launch; FETCH_SIZE x2 for the wide p/m/v stream per MI355X_MICROARCH.md HBM)'
+                                    % pmc.get('build', '?')) if rec else None),
                 'avg_launch_ms': k['avg_launch_ms'], 'launches_per_step': k['launches_per_step'],
                 'algorithmic_bytes_per_launch': k.get('algorithmic_bytes_per_launch')}
+    for k in kernels:
+        if 'mfma_busy_counter' in k:
+            k['mfma_busy_counter'] = mfma_counter(k['name'])
     with_bytes = [k for k in kernels if k.get('algorithmic_GBps')]
     if pipe is not None and pipe.binned_levels and model_sharded is None:
         # binned table update: the LDS-privatised scatter of the small dense levels runs on its own stream BESIDE the
@@ -396,7 +440,7 @@ def main():
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t1) / reps
         _beat()
-        render = {'workload': '800x800 image, 64+128 samples/ray, chunks of 65536 rays, sharded over %d GPU(s)' % world,
+        render = {'workload': '800x800 image, %d+128 samples/ray, chunks of 65536 rays, sharded over %d GPU(s)' % (sum(STEPS), world),
                   'rays_per_s': H * W / dt, 'ms_per_image': dt * 1e3}
         # the reference's own chunk size (inference.py:66 uses trainer.n_rays-sized chunks; SURVEY C2 lists 16 384 too)
         inf_small = Inferencer(renderer, 16384, 0, 0, 0.1, 0.05, 0.4, [1, 2, 3, 4], 20)
@@ -423,7 +467,10 @@ def main():
                                     'samples/ray, config_base network (L%d F2 T%d, SH4, latent 48, 64-wide MLPs), '
                                     'procedural scene 100 poses 800x800' % (args.rays, sum(STEPS), args.levels, args.table_log2))
                                    + ('' if args.coarse == '64' else ' [NOT the metric config: %s coarse samples]' % args.coarse),
-                       'rays_per_gpu': args.rays, 'global_rays': args.rays * world, 'parallelism': ('dp%d over rays' % world) + (', hash table sharded by level (feature all-to-all)'
+                       'rays_per_gpu': args.rays, 'global_rays': args.rays * world,
+                       'table_mode': ('single_gpu' if world == 1 else
+                                      ('level_sharded' if getattr(model_sharded, 'world', 1) > 1 else 'replicated_fallback')),
+                       'parallelism': ('dp%d over rays' % world) + (', hash table sharded by level (feature all-to-all)'
                                                                     if getattr(model_sharded, 'world', 1) > 1 else '') + fallback_note},
             'roofline': roofline, 'roofline_second': roofline_2, 'cpu_baseline': cpu, 'render': render, 'kernels': kernels,
         }

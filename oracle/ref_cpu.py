@@ -69,6 +69,68 @@ def grid_levels(n_levels, log2_hashmap_size, base_resolution=16, per_level_scale
     return levels, offset
 
 
+def _level_corners(xd, lv):
+    """Corner indices [M,8] (int64, into the flat entry table) and trilinear weights [M,8] (fp32) of one level."""
+    pos = (xd * lv.scale + 0.5).float()          # == fmaf(x, scale, 0.5) (product exact in fp64)
+    cell = torch.floor(pos)
+    w = pos - cell                                # exact in fp32
+    ig = cell.to(torch.int64)
+    idxs, wcs = [], []
+    for c in range(8):
+        wc = torch.ones(xd.shape[0], dtype=torch.float32)
+        corner = []
+        for d in range(3):
+            if (c >> d) & 1:
+                wc = wc * w[:, d]
+                corner.append((ig[:, d] + 1) & MASK32)
+            else:
+                wc = wc * (1 - w[:, d])
+                corner.append(ig[:, d] & MASK32)
+        if lv.hashed:
+            idx = corner[0] ^ ((corner[1] * PRIME_Y) & MASK32) ^ ((corner[2] * PRIME_Z) & MASK32)
+        else:
+            idx = (corner[0] + ((corner[1] * lv.res) & MASK32) + ((corner[2] * ((lv.res * lv.res) & MASK32)) & MASK32)) & MASK32
+        idxs.append(idx % lv.entries + lv.offset)
+        wcs.append(wc)
+    return torch.stack(idxs, 1), torch.stack(wcs, 1)
+
+
+class _EncodeFn(torch.autograd.Function):
+    """hashgrid_encode for inputs that carry no gradient (the training path: the sample points are constants,
+    renderer.py:145).  Same forward arithmetic as the plain-autograd form below; the backward builds the table gradient
+    ONCE (one zero fill + one index_add_ per level) -- plain autograd would materialise one dense table-sized gradient
+    per corner gather, 160 x 1.6 GB per step at config_base, which is what a CPU timing would then measure."""
+
+    @staticmethod
+    def forward(ctx, x01, table, levels, n_features):
+        tab = table.view(-1, n_features)
+        xd = x01.double()
+        outs, saved = [], []
+        for lv in levels:
+            idx, wc = _level_corners(xd, lv)
+            vals = tab[idx.reshape(-1)].view(idx.shape[0], 8, n_features)      # ONE gather per level
+            acc = torch.zeros(x01.shape[0], n_features, dtype=torch.float32)
+            for c in range(8):
+                acc = acc + wc[:, c, None] * vals[:, c]
+            outs.append(acc)
+            saved += [idx, wc]
+        ctx.save_for_backward(*saved)
+        ctx.shape, ctx.F = table.shape, n_features
+        return torch.cat(outs, dim=-1)
+
+    @staticmethod
+    def backward(ctx, dout):
+        F_ = ctx.F
+        grad = torch.zeros(ctx.shape, dtype=torch.float32)
+        g2 = grad.view(-1, F_)
+        saved = ctx.saved_tensors
+        for l in range(len(saved) // 2):
+            idx, wc = saved[2 * l], saved[2 * l + 1]
+            contrib = wc[:, :, None] * dout[:, None, l * F_:(l + 1) * F_]
+            g2.index_add_(0, idx.reshape(-1), contrib.reshape(-1, F_))
+        return None, grad, None, None
+
+
 def hashgrid_encode(x01, table, levels, n_features):
     """x01 [M,3] fp32 in [0,1]; table flat fp32 [total_entries * F] -> [M, L*F].
 
@@ -76,6 +138,9 @@ def hashgrid_encode(x01, table, levels, n_features):
     takes +1 in dimension d iff bit d of c is set; dense levels index x + y*res + z*res^2,
     hashed levels x ^ y*2654435761 ^ z*805459861 (uint32 wrap), both modulo the level size.
     """
+    if not x01.requires_grad:
+        return _EncodeFn.apply(x01, table, levels, n_features)
+    # positions carry a gradient (pose alignment, allign/trainer.py:188): plain autograd through the weights
     tab = table.view(-1, n_features)
     outs = []
     xd = x01.double()
@@ -475,6 +540,36 @@ def invdepth_thresh(weights, z_vals, distribution_area, max_variance_pcd):
     out[torch.abs(d_start - d_end) > max_variance_pcd] = 0
     out[d_mid == 0] = 0
     return out
+
+
+@torch.no_grad()
+def surface_geometry(weights, z_vals, xyzs, rgbs, distribution_area, max_variance_npy, inner_bound):
+    """inference.py:187-214 for one chunk: the sample at which the running weight sum crosses 0.5, kept when the
+    depths of the (0.5 -/+ area/2) crossings lie within max_variance_npy of each other and the point is inside the
+    inner bound.  Returns (points [P,3], colors [P,3], depth_variance [P,1])."""
+    start = cumulative_weights_thresh(weights, 0.5 - distribution_area / 2)
+    mid = cumulative_weights_thresh(weights, 0.5)
+    end = cumulative_weights_thresh(weights, 0.5 + distribution_area / 2)
+    d_start = torch.sum(start * z_vals, dim=-1)
+    d_end = torch.sum(end * z_vals, dim=-1)
+    var = torch.abs(d_start - d_end)[:, None, None].expand(-1, weights.shape[1], 1)
+    mask = (var < max_variance_npy) & mid.to(bool)[..., None] & \
+           (torch.linalg.norm(xyzs, dim=-1, keepdim=True) < inner_bound)
+    points = xyzs[mask.expand(*xyzs.shape)].reshape(-1, 3)
+    colors = rgbs[mask.expand(*rgbs.shape)].reshape(-1, 3)
+    return points, colors, var[mask].reshape(-1, 1)
+
+
+@torch.no_grad()
+def threshold_margin(weights, distribution_area):
+    """Per ray: the smallest distance of the running weight sum (inference.py:99) from any of the three thresholds --
+    rays with a margin well above the GPU/CPU difference of the weights have the same first-crossing samples."""
+    cdf = torch.cumsum(weights, dim=-1)
+    m = None
+    for t in (0.5 - distribution_area / 2, 0.5, 0.5 + distribution_area / 2):
+        d = (cdf - t).abs().min(dim=-1).values
+        m = d if m is None else torch.minimum(m, d)
+    return m
 
 
 # --------------------------------------------------------------------------------------

@@ -276,7 +276,8 @@ def test_train_steps_vs_oracle(name, binned, monkeypatch):
                    betas=(0.9, 0.99), eps=1e-15).attach(net)
     assert bool(net.table_pipeline.binned_levels) == (name == 'base19' and binned == '1')
     lo, lg = [], []
-    for it in range(4):
+    n_steps = 20 if (name, binned) in (('small', '1'), ('base19', '1')) else 4      # a 20-step trace
+    for it in range(n_steps):
         n, h, w, K, E, bg, noise, gt = _batch(10 + it, 96)
         oo.zero_grad()
         img, wts, zs, _ = Ro.render(n, h, w, K, E, bg, noise=noise)
@@ -291,11 +292,26 @@ def test_train_steps_vs_oracle(name, binned, monkeypatch):
         loss_g.backward()
         og.step()
         lg.append(float(loss_g))
-    for a, b in zip(lg, lo):
-        assert abs(a - b) <= 2e-4 * max(1.0, abs(b)), (lg, lo)
+        if it == 0:
+            # after ONE step no sample can have moved to another cell yet: the table's Adam moments must agree with
+            # torch.optim.Adam's entry by entry (m = 0.1 g, v = 0.01 g^2), up to the summation order of the corner updates
+            torch.cuda.synchronize()
+            st1, so1 = og.state[net.encoder.params], oo.state[ora.encoder_params]
+            m1, v1, mo1, vo1 = st1['exp_avg'].cpu(), st1['exp_avg_sq'].cpu(), so1['exp_avg'], so1['exp_avg_sq']
+            # (a fine sample a few 1e-5 next to a cell face may sit in the neighbouring cell on the other side -- the fine
+            # depths agree to 5e-5, not bit for bit -- so a small share of entries differs; their corner weights are ~0)
+            for a_, b_, what in ((m1, mo1, 'exp_avg'), (v1, vo1, 'exp_avg_sq')):
+                bad = (a_ - b_).abs() > 1e-3 * b_.abs() + 1e-4 * float(b_.abs().max())
+                assert float(bad.float().mean()) < 5e-3, (what, float(bad.float().mean()))
+                assert float((a_ - b_).norm() / b_.norm()) < 2e-2, what
+            assert int((m1 != 0).sum()) > 1000 and float(((m1 != 0) != (mo1 != 0)).float().mean()) < 5e-3
+    # the first steps agree to the parity bar; later ones drift apart slowly (Adam with eps = 1e-15 turns summation noise on
+    # near-zero gradients into +-lr parameter steps), so the bar widens with the step count
+    for k, (a, b) in enumerate(zip(lg, lo)):
+        assert abs(a - b) <= (2e-4 if k < 4 else 2e-3) * max(1.0, abs(b)), (k, lg, lo)
     # (lr 1e-3 x 4 steps: a weight whose tiny gradient flips sign with the summation order moves by up to 2 lr per step)
     torch.testing.assert_close(net.sigma_net.params.detach().cpu(), ora.sigma_params.detach(), rtol=0,
-                               atol=3e-3 if name == 'base19' else 2e-3)
+                               atol=(3e-3 if name == 'base19' else 2e-3) * (n_steps / 4))
     # Adam invariants of the table: a parameter that ever saw a gradient has both moments, and the moments agree with
     # the oracle's (torch.optim.Adam) wherever they are not summation noise.  (The first pipelined step once lost its
     # moments to a late zero-fill: v = 0 under m != 0 divides by eps on the next step.)
@@ -360,11 +376,16 @@ def test_extract_dense_geometry_vs_oracle():
     pts_g, col_g = ex.extract_dense_geometry(7, 800, 800, K.cuda(), E.cuda(), mask=full.cuda())
     pts_o, col_o = ref_cpu.extract_dense_geometry(ora, full, 12, 500, thresh, 2.5)
     safe = (sig_all - thresh).abs() > 1e-4 * float(sig_all.abs().max())   # away from the threshold the sets must agree
-    key = lambda p: set(map(tuple, (p * 1e4).round().to(torch.int64).tolist()))
-    kg, ko, ks = key(pts_g), key(pts_o), key(grid[safe])
-    assert (kg & ks) == (ko & ks) and len(ko) > 0
-    if pts_g.shape == pts_o.shape and torch.equal(pts_g, pts_o):
-        torch.testing.assert_close(col_g, col_o, rtol=0, atol=1e-5)
+    key = lambda p: list(map(tuple, (p * 1e4).round().to(torch.int64).tolist()))
+    kg, ko, ks = key(pts_g), key(pts_o), set(key(grid[safe]))
+    assert (set(kg) & ks) == (set(ko) & ks) and len(ko) > 0
+    # colours of every point both sides kept, whatever the order and whatever happened next to the threshold
+    ig, io = {k: i for i, k in enumerate(kg)}, {k: i for i, k in enumerate(ko)}
+    common = sorted(set(kg) & set(ko))
+    assert len(common) >= len(set(ko) & ks) > 100
+    torch.testing.assert_close(col_g[[ig[k] for k in common]], col_o[[io[k] for k in common]], rtol=0, atol=1e-5)
+    # order: ascending voxel index, as the reference's batch loop produces it
+    assert [k for k in kg if k in ks] == [k for k in ko if k in ks]
 
 
 def test_chunked_backward_matches_unchunked():

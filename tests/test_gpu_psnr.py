@@ -1,0 +1,20 @@
+"""PSNR delta between the HIP path and the CPU oracle after an identical training budget ("matching PSNR on
+the synthetic scene"): same initial weights, same ray batches, same stratification noise, same Adam groups, 60
+iterations of 1024 rays on 20 views of the analytic scene; then both render one training view.  Bar: 0.05 dB."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_psnr_delta_after_identical_training():
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import psnr_run
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    r = psnr_run.delta_run(res=64, n_img=20, L=8, T=15, iters=60, n_rays=1024)
+    assert r['psnr_hip'] > 15.0, r                      # the budget is enough to learn something
+    assert abs(r['psnr_delta']) <= 0.05, r
+    assert r['max_abs_loss_diff'] <= 5e-4, r

@@ -102,3 +102,26 @@ def test_grid_level_table():
     assert [lv.res for lv in levels[:9]] == [16, 23, 31, 43, 59, 81, 112, 154, 213]
     assert [lv.hashed for lv in levels] == [False] * 9 + [True] * 11
     assert total == 200132568
+
+
+def test_inferencer_entry_points_vs_reference_golden():
+    """tests/golden/infer.npz holds what the REFERENCE's Inferencer.render_image / render_invdepth_thresh /
+    extract_surface_geometry (inference.py:54-223) returned on the CPU (tests/golden/make_golden_infer.py): the oracle's
+    restatements must reproduce them -- image / inverse depth from the same rays, field and noise; thresholded depth and
+    surface points bit for bit from the same weights."""
+    g = load_golden('infer')
+    field = ref_cpu.AnalyticField(centers=g['field_centers'].tolist(), widths=g['field_widths'].tolist(),
+                                  peaks=g['field_peaks'].tolist(), floor=float(g['field_floor']))
+    R = ref_cpu.OracleRenderer(field, 2, 2.5, [1.6, 4.8], [64], 128, 0.2)
+    flat = lambda t, *s: t.reshape(-1, *s)
+    with torch.no_grad():
+        img, w, _, aux = R.render(flat(g['n']), flat(g['h']), flat(g['w']), flat(g['K'], 3, 3), flat(g['E'], 4, 4),
+                                  torch.ones(3), noise=g['noise'])
+    assert torch.equal(w, g['weights']) and torch.equal(aux['z_vals'], g['z_vals'])
+    torch.testing.assert_close(img, flat(g['image'], 3), rtol=0, atol=1e-6)
+    torch.testing.assert_close(aux['invdepth'], flat(g['invdepth']), rtol=0, atol=1e-6)
+    got = ref_cpu.invdepth_thresh(g['weights'], g['z_vals'], 0.4, 0.05)
+    assert torch.equal(got, flat(g['invdepth_thresh'])) and int((got > 0).sum()) == 33
+    pts, col, var = ref_cpu.surface_geometry(g['weights'], g['z_vals'], g['xyzs'], g['rgbs'], 0.4, 0.1, 2)
+    assert pts.shape[0] == 46
+    assert torch.equal(pts, g['points']) and torch.equal(col, g['colors']) and torch.equal(var, g['depth_variance'])

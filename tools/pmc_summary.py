@@ -41,6 +41,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--steps', type=int, required=True, help='training steps executed by the profiled command')
     ap.add_argument('--out', default=None)
+    ap.add_argument('--build', default='?', help='tag of the profiled build, recorded in the output')
     ap.add_argument('--adam-grid', type=int, default=4194304, help='Grid_Size of the Adam launch on one hashed level')
     ap.add_argument('--levels-per-chunk', type=int, default=15, help='single-level scatter_kernel launches per backward chunk')
     ap.add_argument('--hashed-per-chunk', type=int, default=11, help='of which hashed levels (issued first)')
@@ -93,7 +94,7 @@ def main():
         if cls == 'nerf_table_update_binned':        # wide p/m/v stream counted at one half, the item reads in full
             fetch = 2 * max(0.0, fetch - a.binned_item_bytes) + min(fetch, a.binned_item_bytes)
         pl[cls] = {'hbm_bytes': fetch + write, 'fetch_bytes': fetch, 'write_bytes': write}
-    out = {'per_launch': pl}
+    out = {'per_launch': pl, 'build': a.build}
     for entry in tot:
         fetch = tot[entry].get('FETCH_SIZE', 0.0) * 1024 / a.steps * (2 if entry in FETCH_X2 else 1)
         write = tot[entry].get('WRITE_SIZE', 0.0) * 1024 / a.steps
@@ -104,7 +105,7 @@ def main():
     for k, v in sorted(pl.items()):
         print('%-52s %8.1f MB/launch (fetch %7.1f, write %7.1f)' % (k, v['hbm_bytes'] / 1e6, v['fetch_bytes'] / 1e6,
                                                                    v['write_bytes'] / 1e6))
-    for k, v in sorted(((k, v) for k, v in out.items() if k != 'per_launch'), key=lambda kv: -kv[1]['hbm_bytes_per_step']):
+    for k, v in sorted(((k, v) for k, v in out.items() if k not in ('per_launch', 'build')), key=lambda kv: -kv[1]['hbm_bytes_per_step']):
         print('%-28s %8.3f GB/step  (fetch %7.3f, write %7.3f)  %5.1f launches/step  %7.3f ms/step serialized' % (
             k, v['hbm_bytes_per_step'] / 1e9, v['fetch_bytes_per_step'] / 1e9, v['write_bytes_per_step'] / 1e9,
             v['launches_per_step'], v['serialized_ms_per_step']))

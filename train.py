@@ -10,7 +10,9 @@ import torch
 from nerf_amd import parallel
 from nerf_amd.config import configurator
 from nerf_amd.inference import Inferencer
+from nerf_amd.loaders.camera_geometry_loader import CameraGeometryLoader
 from nerf_amd.loaders.procedural import ProceduralSceneLoader
+from nerf_amd.loaders.synthetic_scans import make_scans
 from nerf_amd.logger import Logger
 from nerf_amd.nets import NeRFNetwork
 from nerf_amd.optim import FusedAdam
@@ -21,11 +23,22 @@ if __name__ == '__main__':
     cfg = configurator('./configs/config_base.yaml')
     rank, world, local = parallel.init_from_env()
     torch.cuda.set_device(local)
-    logger = Logger(root_dir=cfg.log.root_dir if rank == 0 else None, cfg=cfg, verbose=rank == 0)
+    # (config_bothsides.yaml nests log.root_dir under `scene`, as the reference's file does: honour it)
+    root_dir = cfg.scene.get('log', {}).get('root_dir', cfg.log.root_dir)
+    logger = Logger(root_dir=root_dir if rank == 0 else None, cfg=cfg, verbose=rank == 0)
 
     logger.log('Initiating Dataloader...')
-    dataloader = ProceduralSceneLoader(cfg.scene.get('n_images', 100), cfg.scene.get('image_size', 800),
-                                       cfg.scene.get('image_size', 800), batch_seed=1000 + rank)
+    paths = [str(p) for p in cfg.scene.scene_paths]
+    if paths == ['procedural']:
+        size = cfg.scene.get('image_size', int(1600 * cfg.scene.image_scale))
+        dataloader = ProceduralSceneLoader(cfg.scene.get('n_images', 100), size, size, batch_seed=1000 + rank)
+    elif all(p.startswith('synthetic_scan') for p in paths):
+        dataloader = CameraGeometryLoader.from_arrays(make_scans(paths, cfg.scene.transforms, cfg.scene.image_scale),
+                                                      batch_seed=1000 + rank)
+    else:       # the reference's wiring (train.py:30-35): scan files read by the camera_geometry package
+        dataloader = CameraGeometryLoader(scene_paths=cfg.scene.scene_paths, frame_ranges=cfg.scene.frame_ranges,
+                                          transforms=cfg.scene.transforms, image_scale=cfg.scene.image_scale,
+                                          batch_seed=1000 + rank)
 
     logger.log('Initilising Model...')
     model = NeRFNetwork(
