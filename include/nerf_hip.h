@@ -124,6 +124,16 @@ int64_t nerf_mlp_bwd_workspace_floats(const int32_t* dims, int n_layers, int64_t
 int nerf_mlp_bwd(const float* params, const int32_t* dims, int n_layers, const float* x, const float* dout, int64_t n_rows,
                  float* dx, float* dparams, float* workspace, int64_t workspace_floats, void* stream);
 
+/* nerf_mlp_bwd without a workspace argument.  NO COUNTERPART IN THE REFERENCE: it exists for callers that cannot
+ * allocate device memory -- code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  The
+ * workspace is a static 18 MiB device array inside the library (every GPU the library runs on holds its own copy
+ * until the process ends); the call allocates and frees nothing.  n_rows is limited by that array: the floats
+ * nerf_mlp_bwd_workspace_floats reports must not exceed 4 718 592 (9162 rows for 79 -> 64 -> 64 -> 3), else
+ * NERF_EINVAL with a message naming the limit.  All calls on one GPU share the array: calls that overlap on one GPU
+ * (two streams, two threads) race.  Same results as nerf_mlp_bwd. */
+int nerf_mlp_bwd_noalloc(const float* params, const int32_t* dims, int n_layers, const float* x, const float* dout,
+                         int64_t n_rows, float* dx, float* dparams, void* stream);
+
 /* ---- fused field network ---- */
 /* NeRFNetwork.density (nets.py:148-164): normalise, hash-grid encode, sigma MLP, relu. */
 int nerf_density_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const float* table, const float* sigma_params,

@@ -62,6 +62,7 @@ SIGNATURES = {
     'nerf_mlp_fwd': (_I, [_P, C.POINTER(C.c_int32), _I, _P, _I64, _P, _P]),
     'nerf_mlp_bwd_workspace_floats': (_I64, [C.POINTER(C.c_int32), _I, _I64]),
     'nerf_mlp_bwd': (_I, [_P, C.POINTER(C.c_int32), _I, _P, _P, _I64, _P, _P, _P, _I64, _P]),
+    'nerf_mlp_bwd_noalloc': (_I, [_P, C.POINTER(C.c_int32), _I, _P, _P, _I64, _P, _P, _P]),
     'nerf_density_fwd': (_I, [_G, _N, _P, _P, _S, _P, _P, _P]),
     'nerf_field_fwd': (_I, [_G, _N, _P, _P, _P, _P, _I64, _S, _P, _P, _P, _P, _P]),
     'nerf_field_bwd': (_I, [_G, _N, _P, _P, _P, _P, _I64, _S, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

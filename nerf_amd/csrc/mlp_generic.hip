@@ -133,3 +133,53 @@ extern "C" int nerf_mlp_bwd(const float* params, const int32_t* dims, int n_laye
     }
     return nerf_launch_status("nerf_mlp_bwd");
 }
+
+// ---- the same call for callers that cannot allocate -------------------------------------------------------------------
+// nerf_mlp_bwd needs a caller-provided workspace (activations of every layer + three [rows][128] gradient buffers).  A
+// caller under HIP graph capture, in a tight serving loop or behind a harness that forbids hipMalloc has nowhere to get
+// one from: this variant keeps the workspace in a file-scope device array instead.  Every GPU the library runs on holds
+// its own copy of the array (18 MiB, until the process ends) at its own address; host code must never pass the array's
+// NAME to a kernel (that is a host-side stand-in, not a device address): the address is looked up once per device with
+// hipGetSymbolAddress and only that pointer is used.
+namespace {
+constexpr int64_t kScratchFloats = 4718592;       // 18 MiB: e.g. 9162 rows of the colour net (79 -> 64 -> 64 -> 3)
+__device__ __align__(256) float scratch[kScratchFloats];
+constexpr int kMaxDevices = 64;
+float* g_scratch_ptr[kMaxDevices] = {};
+}  // namespace
+
+static int64_t noalloc_max_rows(const int32_t* dims, int n_layers) {
+    int64_t per_row = 3 * kMaxW;
+    for (int l = 1; l <= n_layers; ++l) per_row += dims[l];
+    return kScratchFloats / per_row;
+}
+
+extern "C" int nerf_mlp_bwd_noalloc(const float* params, const int32_t* dims, int n_layers, const float* x, const float* dout,
+                                    int64_t n_rows, float* dx, float* dparams, void* stream) {
+    NERF_REQUIRE(!check_dims(dims, n_layers) && n_rows >= 0, "layer widths must be in [1,128], 1..8 layers");
+    const int64_t need = nerf_mlp_bwd_workspace_floats(dims, n_layers, n_rows);
+    if (need > kScratchFloats) {
+        nerf_set_error("nerf_mlp_bwd_noalloc: %lld rows need %lld floats of scratch, the built-in buffer holds %lld (at most %lld "
+                       "rows for these layer widths); use nerf_mlp_bwd with a workspace", (long long)n_rows, (long long)need,
+                       (long long)kScratchFloats, (long long)noalloc_max_rows(dims, n_layers));
+        return NERF_EINVAL;
+    }
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+        nerf_set_error("nerf_mlp_bwd_noalloc: hipGetDevice: %s", hipGetErrorString(e));
+        return e != hipSuccess ? (int)e : NERF_EINVAL;
+    }
+    float* ws = __atomic_load_n(&g_scratch_ptr[dev], __ATOMIC_ACQUIRE);
+    if (!ws) {      // first call on this device (it is the current one): this device's copy of the array
+        e = hipGetSymbolAddress((void**)&ws, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ws) {
+            nerf_set_error("nerf_mlp_bwd_noalloc: hipGetSymbolAddress: %s", hipGetErrorString(e));
+            return e != hipSuccess ? (int)e : NERF_EINVAL;
+        }
+        __atomic_store_n(&g_scratch_ptr[dev], ws, __ATOMIC_RELEASE);
+    }
+    // (nothing in the workspace has to start at zero: the forward pass rewrites every activation, every layer rewrites dz
+    // and the gradient ping-pong buffers before reading them)
+    return nerf_mlp_bwd(params, dims, n_layers, x, dout, n_rows, dx, dparams, ws, kScratchFloats, stream);
+}
