@@ -4,9 +4,9 @@
 // dense Adam pass (train.py:84-88) -- moves 32 B per table parameter through HBM (p, g, m, v read; p, m, v written;
 // g cleared) and pays the memory-side atomic rate for every corner update.  Here the corner updates of a step are
 // first BINNED by table partition (a counting sort: count, scan, fill -- no global atomics, a deterministic number of
-// items), then one workgroup per partition (16 K floats = 64 KB of LDS) sums its bin into LDS with ds_add_f32 and
-// streams p, m, v through the Adam update with the gradient read from LDS: 24 B per parameter, no gradient array,
-// no memory-side atomics.  The update rule is exactly nerf_adam_step's (adam_common.h); only the summation order of
+// items), then every partition (16 K floats, cut at multiples of 64 KB from the table's base) is summed in LDS with
+// ds_add_f32 by four workgroups, a quarter each, which stream p, m, v through the Adam update with the gradient read
+// from LDS: 24 B per parameter, no gradient array, no memory-side atomics.  The update rule is exactly nerf_adam_step's (adam_common.h); only the summation order of
 // the corner contributions differs (as it does between any two runs of the atomic scatter).
 //
 // Used for the levels that are large enough to fill many partitions (the hashed levels and the big dense ones); the
@@ -24,16 +24,12 @@ namespace {
 #ifndef NERF_PART_FLOATS
 #define NERF_PART_FLOATS 16384
 #endif
-#ifndef NERF_UPD_THREADS
-#define NERF_UPD_THREADS 1024
-#endif
 constexpr int kPartFloats = NERF_PART_FLOATS;   // floats of one table partition (64 KB of LDS in the update kernel)
 #ifndef NERF_BIN_CHUNK
 #define NERF_BIN_CHUNK 16384
 #endif
 constexpr int kBinChunkPts = NERF_BIN_CHUNK;   // points per workgroup of the count / fill passes
 constexpr int kBinThreads = 1024;
-constexpr int kUpdThreads = NERF_UPD_THREADS;
 constexpr int kMaxBinsPerLevel = 8192;    // LDS histogram of the count / fill passes: 32 KB
 static_assert(kPartFloats % 4 == 0 && kPartFloats <= 65536, "an item's partition-local offset is stored as uint16");
 
@@ -42,6 +38,12 @@ struct BinPlan {
     int level[NERF_MAX_LEVELS];
     int col[NERF_MAX_LEVELS];                    // first d(features) column of the level
     uint32_t nbins[NERF_MAX_LEVELS];
+    // Partitions are cut at multiples of kPartFloats of the ABSOLUTE float index in the table, not of the level's own:
+    // shift = (first float of the level) % kPartFloats, a level-local float x lies in partition (x + shift) / kPartFloats
+    // at offset (x + shift) % kPartFloats.  The p, m, v chunks of the update pass then start at multiples of 16 KB from
+    // the tensors' bases whatever the level offsets are (the same stream runs 1.64 ms aligned, 1.75 ms at config_base's
+    // offset of level 5, tools/stream3_bench.hip); a level's first and last partition may be short.
+    uint32_t shift[NERF_MAX_LEVELS];
     uint32_t part_base[NERF_MAX_LEVELS + 1];     // running sum of nbins: workgroup id of the update kernel -> level slot
     int64_t hist_off[NERF_MAX_LEVELS];           // in uint32 units: the slot's [workgroup][bin] histogram / offsets
     int64_t item_off[NERF_MAX_LEVELS];           // in items: the slot's 8 * n_points items
@@ -76,13 +78,14 @@ __global__ __launch_bounds__(kBinThreads) void bin_count_kernel(GridDev g, NerfP
     for (uint32_t i = threadIdx.x; i < nb; i += kBinThreads) lh[i] = 0u;
     __syncthreads();
     const LevelP lp = plan_level(g, l);
+    const uint32_t shift = plan.shift[slot];
     const int64_t p0 = (int64_t)blockIdx.x * kBinChunkPts;
     const int64_t p1 = p0 + kBinChunkPts < M ? p0 + kBinChunkPts : M;
     for (int64_t p = p0 + threadIdx.x; p < p1; p += kBinThreads) {
         const PointIn q = fetch_point(src, p, false);
         const Corners c = level_corners(lp, q.x, q.y, q.z);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) atomicAdd(&lh[(c.idx[k] * (uint32_t)F) / kPartFloats], 1u);
+        for (int k = 0; k < 8; ++k) atomicAdd(&lh[(c.idx[k] * (uint32_t)F + shift) / kPartFloats], 1u);
     }
     __syncthreads();
     uint32_t* dst = hist + plan.hist_off[slot] + (int64_t)blockIdx.x * nb;      // [workgroup][bin]: coalesced
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_fill_kernel(GridDev g, NerfPo
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const uint32_t fl = c.idx[k] * (uint32_t)F;
+            const uint32_t fl = c.idx[k] * (uint32_t)F + plan.shift[slot];
             const uint32_t pos = atomicAdd(&cur[fl / kPartFloats], 1u);
             ii[pos] = (uint16_t)(fl % kPartFloats);
             if (F == 2) { f32x2 t; t.x = c.w[k] * d[0]; t.y = c.w[k] * d[F - 1]; *(f32x2*)(iv + (int64_t)pos * 2) = t; }
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_fill_sorted_kernel(GridDev g,
             for (int f = 0; f < F; ++f) d[f] = dp[f];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const uint32_t fl = c.idx[k] * (uint32_t)F;
+                const uint32_t fl = c.idx[k] * (uint32_t)F + plan.shift[slot];
                 bin[k] = fl / kPartFloats;
                 loc[k] = fl % kPartFloats;
                 rank[k] = atomicAdd(&cnt[bin[k]], 1u);
@@ -299,84 +302,110 @@ __global__ __launch_bounds__(kBinThreads) void bin_fill_sorted_kernel(GridDev g,
     }
 }
 
-// pass 4: one workgroup per partition: sum the bin into LDS, then Adam over the partition with the gradient from LDS
+// pass 4: FOUR 256-thread workgroups per partition, each owning a quarter of it (4096 floats, 16 KB of LDS): sum the
+// quarter's share of the bin into LDS, then Adam over the quarter with the gradient from LDS.
+// What the memory system rewards here is many small workgroups in flight: the bare p, m, v stream runs at 5.9 TB/s from
+// 256-thread workgroups of 16 KB per array against 5.0 TB/s from 1024-thread ones holding a whole 64 KB partition
+// (tools/stream3_bench.hip), and with 16 KB of LDS a CU holds seven workgroups, so the short LDS phase of one hides under
+// the streams of the others.  Every quarter scans the whole bin (2- and 8-byte loads, mostly L2 hits after the first
+// quarter's pass) and keeps the items that fall into its quarter.  Block b takes quarter b % 4 of partition b / 4:
+// giving the four quarters of a partition to ONE XCD (block indices equal modulo 8), so that the bin is fetched from HBM
+// once, measured SLOWER (2.00 vs 1.92 ms on one box): the stream wants consecutive blocks on consecutive addresses.
+// (Measured on one box, update pass alone: quarters 1.86 ms; halves 1.96; eighths 1.89; quarters with every item's
+// values requested together with its index, before the quarter test, 1.90.)
+constexpr int kSubs = 4;
+constexpr int kSubFloats = kPartFloats / kSubs;
+constexpr int kSplitThreads = 256;
+
 template <int F>
-__global__ __launch_bounds__(kUpdThreads) void table_update_kernel(GridDev g, BinPlan plan,
-                                                                   const uint32_t* __restrict__ bin_start,
-                                                                   const uint16_t* __restrict__ item_idx,
-                                                                   const float* __restrict__ item_val, int64_t n_items_level,
-                                                                   float* __restrict__ p, float* __restrict__ m,
-                                                                   float* __restrict__ v, AdamK k,
-                                                                   const double* __restrict__ skip) {
-    extern __shared__ __attribute__((aligned(16))) float acc[];
+__global__ __launch_bounds__(kSplitThreads) void table_update_kernel(GridDev g, BinPlan plan,
+                                                                     const uint32_t* __restrict__ bin_start,
+                                                                     const uint16_t* __restrict__ item_idx,
+                                                                     const float* __restrict__ item_val,
+                                                                     int64_t n_items_level, float* __restrict__ p,
+                                                                     float* __restrict__ m, float* __restrict__ v,
+                                                                     AdamK k, const double* __restrict__ skip) {
+    static_assert(kSubFloats % (4 * kSplitThreads) == 0, "whole quads per thread");
+    __shared__ __attribute__((aligned(16))) float acc[kSubFloats];
     if (skip && *skip != 0.0) return;       // non-finite loss this step (nerf_losses sums[5]): the step is dropped
-    const uint32_t part = blockIdx.x;
+    constexpr int T = kSplitThreads, kQuads = kSubFloats / 4 / T;
+    const uint32_t part = blockIdx.x / kSubs, sub = blockIdx.x % kSubs;
+    // level slot of the partition: a count of independent compares (no chain of dependent kernel-argument loads)
     int slot = 0;
-    while (slot + 1 < plan.count && part >= plan.part_base[slot + 1]) ++slot;
+#pragma unroll
+    for (int s_ = 1; s_ < NERF_MAX_LEVELS; ++s_) slot += (s_ < plan.count && part >= plan.part_base[s_]) ? 1 : 0;
     const uint32_t bin = part - plan.part_base[slot];
     const int l = plan.level[slot];
     const int64_t level_floats = (int64_t)g.entries[l] * F;
-    const int64_t f0 = (int64_t)bin * kPartFloats;
-    const int n_here = (int)(level_floats - f0 < kPartFloats ? level_floats - f0 : kPartFloats);
-    const int n4 = n_here >> 2;
+    // level-local float index of this quarter's first LDS word (negative in the short first partition of a level)
+    const int64_t f0 = (int64_t)bin * kPartFloats - (int64_t)plan.shift[slot] + (int64_t)sub * kSubFloats;
+    if (f0 >= level_floats || f0 + kSubFloats <= 0) return;
+    const int q_lo = f0 < 0 ? (int)((-f0) >> 2) : 0;                       // quads [q_lo, q_hi) of the quarter exist
+    const int q_hi = (int)((level_floats - f0 < kSubFloats ? level_floats - f0 : kSubFloats) >> 2);
+    const int tid = threadIdx.x;
     const f4 zero = {0.f, 0.f, 0.f, 0.f};
     f4* acc4 = (f4*)acc;
-    for (int i = threadIdx.x; i < kPartFloats / 4; i += kUpdThreads) acc4[i] = zero;
-    __syncthreads();
+    // this thread's p, m, v: requested first, they arrive while the bin is summed
+    const int64_t base4 = ((int64_t)g.offset[l] * F + f0) >> 2;            // (arithmetic shift: f0 may be negative)
+    f4 pq[kQuads], mq[kQuads], vq[kQuads];
+#pragma unroll
+    for (int u = 0; u < kQuads; ++u) {
+        const int i = tid + u * T;
+        const int64_t a = base4 + ((i >= q_lo && i < q_hi) ? i : q_lo);
+        pq[u] = __builtin_nontemporal_load((const f4*)p + a);
+        mq[u] = __builtin_nontemporal_load((const f4*)m + a);
+        vq[u] = __builtin_nontemporal_load((const f4*)v + a);
+    }
+#pragma unroll
+    for (int u = 0; u < kQuads; ++u) acc4[tid + u * T] = zero;
+    __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0) only: the loads above stay in flight across the barrier
+    __builtin_amdgcn_s_barrier();
     const uint32_t* bs = bin_start + plan.part_base[slot] + slot;
     // (clamped: a workspace that was not filled for these levels / this point count must not turn into wild reads)
     const uint32_t n_items = (uint32_t)n_items_level;
     uint32_t b0 = 0, b1 = 0;            // no points: a plain Adam step with a zero gradient, the workspace is not read
     if (n_items) { b0 = bs[bin] < n_items ? bs[bin] : n_items; b1 = bs[bin + 1] < n_items ? bs[bin + 1] : n_items; }
     const int64_t i0 = plan.item_off[slot] + b0, i1 = plan.item_off[slot] + (b1 > b0 ? b1 : b0);
-    // (several items per thread and round with their loads issued together measured no gain: two workgroups per CU
-    // already cover each other's latency in this phase)
-    for (int64_t i = i0 + threadIdx.x; i < i1; i += kUpdThreads) {
-        int li = item_idx[i];
-        li = li <= kPartFloats - F ? li : kPartFloats - F;
-        if (F == 2) {
-            const f32x2 t = *(const f32x2*)(item_val + i * 2);
-            atomicAdd(acc + li, t.x);
-            atomicAdd(acc + li + 1, t.y);
-        } else {
+    const int lo = (int)sub * kSubFloats;
+    constexpr int U = 4;                // four items per thread and round, their loads issued together
+    int64_t i = i0 + tid;
+    for (; i + (U - 1) * T < i1; i += U * T) {
+        int li[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) li[u] = (int)item_idx[i + u * T] - lo;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if ((unsigned)li[u] <= (unsigned)(kSubFloats - F)) {
+                if (F == 2) {
+                    const f32x2 t = *(const f32x2*)(item_val + (i + u * T) * 2);
+                    atomicAdd(acc + li[u], t.x);
+                    atomicAdd(acc + li[u] + 1, t.y);
+                } else {
+#pragma unroll
+                    for (int f = 0; f < F; ++f) atomicAdd(acc + li[u] + f, item_val[(i + u * T) * F + f]);
+                }
+            }
+        }
+    }
+    for (; i < i1; i += T) {
+        const int li = (int)item_idx[i] - lo;
+        if ((unsigned)li <= (unsigned)(kSubFloats - F)) {
 #pragma unroll
             for (int f = 0; f < F; ++f) atomicAdd(acc + li + f, item_val[i * F + f]);
         }
     }
-    __syncthreads();
-    const int64_t base = (int64_t)g.offset[l] * F + f0;
-    f4* p4 = (f4*)(p + base);
-    f4* m4 = (f4*)(m + base);
-    f4* v4 = (f4*)(v + base);
-    int i = threadIdx.x;
-    // a full partition is kQuads (four) quads per thread: all twelve loads are issued before the first Adam update (the step
-    // is 0.06 ms shorter than with one quad per loop round, although the kernel alone is 2 % slower)
-    constexpr int kQuads = kPartFloats / 4 / kUpdThreads;
-    for (; i + (kQuads - 1) * kUpdThreads < n4; i += kQuads * kUpdThreads) {
-        f4 pq[kQuads], mq[kQuads], vq[kQuads];
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
 #pragma unroll
-        for (int u = 0; u < kQuads; ++u) {
-            pq[u] = __builtin_nontemporal_load(p4 + i + u * kUpdThreads);
-            mq[u] = __builtin_nontemporal_load(m4 + i + u * kUpdThreads);
-            vq[u] = __builtin_nontemporal_load(v4 + i + u * kUpdThreads);
-        }
-#pragma unroll
-        for (int u = 0; u < kQuads; ++u) {
-            const f4 gq = acc4[i + u * kUpdThreads];
+    for (int u = 0; u < kQuads; ++u) {
+        const int ii = tid + u * T;
+        if (ii >= q_lo && ii < q_hi) {
+            const f4 gq = acc4[ii];
             adam4(pq[u], gq, mq[u], vq[u], k);
-            __builtin_nontemporal_store(pq[u], p4 + i + u * kUpdThreads);
-            __builtin_nontemporal_store(mq[u], m4 + i + u * kUpdThreads);
-            __builtin_nontemporal_store(vq[u], v4 + i + u * kUpdThreads);
+            __builtin_nontemporal_store(pq[u], (f4*)p + base4 + ii);
+            __builtin_nontemporal_store(mq[u], (f4*)m + base4 + ii);
+            __builtin_nontemporal_store(vq[u], (f4*)v + base4 + ii);
         }
-    }
-    for (; i < n4; i += kUpdThreads) {
-        f4 pa = __builtin_nontemporal_load(p4 + i), ma = __builtin_nontemporal_load(m4 + i);
-        f4 va = __builtin_nontemporal_load(v4 + i);
-        const f4 ga = acc4[i];
-        adam4(pa, ga, ma, va, k);
-        __builtin_nontemporal_store(pa, p4 + i);
-        __builtin_nontemporal_store(ma, m4 + i);
-        __builtin_nontemporal_store(va, v4 + i);
     }
 }
 
@@ -400,8 +429,10 @@ int make_plan(const char* fn, const NerfGridCfg* grid, const NerfLevelSet* level
         for (int j = 0; j < i; ++j)
             if (levels->level[j] == l) { nerf_set_error("%s: level listed twice", fn); return NERF_EINVAL; }
         const int64_t floats = (int64_t)grid->entries[l] * F;
-        const int64_t nb = ceil_div64(floats, kPartFloats);
-        if ((floats & 3) || (((int64_t)grid->offset[l] * F) & 3) || nb > kMaxBinsPerLevel || (uint64_t)grid->entries[l] * F >= (1ull << 32)) {
+        const int64_t shift = ((int64_t)grid->offset[l] * F) % kPartFloats;
+        const int64_t nb = ceil_div64(floats + shift, kPartFloats);
+        if ((floats & 3) || (((int64_t)grid->offset[l] * F) & 3) || nb > kMaxBinsPerLevel ||
+            (uint64_t)grid->entries[l] * F + kPartFloats >= (1ull << 32)) {
             nerf_set_error("%s: unsupported: level %d (needs a multiple of 4 floats at a 16-byte offset and at most %d "
                            "partitions of %d floats)", fn, l, kMaxBinsPerLevel, kPartFloats);
             return NERF_EUNSUPPORTED;
@@ -410,6 +441,7 @@ int make_plan(const char* fn, const NerfGridCfg* grid, const NerfLevelSet* level
         plan->col[i] = cols ? cols[i] : i * F;
         if (plan->col[i] < 0) { nerf_set_error("%s: negative gradient column", fn); return NERF_EINVAL; }
         plan->nbins[i] = (uint32_t)nb;
+        plan->shift[i] = (uint32_t)shift;
         plan->part_base[i] = parts;
         plan->hist_off[i] = hist;
         plan->item_off[i] = items;
@@ -513,15 +545,9 @@ extern "C" int nerf_table_update_binned_guarded(const NerfGridCfg* grid, const N
     const AdamK k = make_adam_k(lr, beta1, beta2, eps, weight_decay, step, grad_scale);
     hipStream_t st = (hipStream_t)stream;
     const unsigned nb = plan.part_base[plan.count];
-    const int lds_bytes = kPartFloats * (int)sizeof(float);
 #define UPDATE(FF)                                                                                                     \
-    do {                                                                                                               \
-        auto kern = table_update_kernel<FF>;                                                                           \
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);  \
-        if (e != hipSuccess) { nerf_set_error("nerf_table_update_binned: LDS attribute: %s", hipGetErrorString(e)); return (int)e; } \
-        kern<<<nb, kUpdThreads, lds_bytes, st>>>(g, plan, bin_start, item_idx, item_val, 8 * n_points, table, exp_avg,   \
-                                                 exp_avg_sq, k, skip_flag); \
-    } while (0)
+    table_update_kernel<FF><<<nb * kSubs, kSplitThreads, 0, st>>>(g, plan, bin_start, item_idx, item_val, 8 * n_points, table,  \
+                                                                  exp_avg, exp_avg_sq, k, skip_flag)
     switch (grid->n_features) {
         case 1: UPDATE(1); break;
         case 2: UPDATE(2); break;
