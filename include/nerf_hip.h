@@ -98,6 +98,19 @@ int64_t nerf_grid_cfg_init(NerfGridCfg* cfg, int n_levels, int n_features, int l
 int64_t nerf_sigma_param_count(const NerfGridCfg* grid, const NerfNetCfg* net);
 int64_t nerf_color_param_count(const NerfNetCfg* net);
 
+/* ---- training batch: loaders/camera_geometry_loader.py:112-117 (get_random_batch) + :91-108 + :68-88 ----
+ * One launch draws `batch` rays (image n, row h, column w ~ uniform; Philox4x32-10, key = seed, counter = (ray,
+ * `counter`): a batch is a pure function of (seed, counter)), gathers their calibration from the per-image stores
+ * (`extrinsics` already re-centred as at :95) and forms the ground truth: uint8 / 255, RGBA blended over ONE random
+ * background colour per batch (:72,81), written to color_bg[3].  images [n_images,H,W,channels] uint8, channels 3 or 4,
+ * nullable (then rgb_gt is the loader's pseudo-colour ((h, w, h+w) % 256) / 255); depths [n_images,H,W] nullable with
+ * depth [batch] nullable. */
+int nerf_sample_batch(const uint8_t* images, const float* depths, const float* intrinsics /*[n_images,3,3]*/,
+                      const float* extrinsics /*[n_images,4,4]*/, int64_t n_images, int H, int W, int channels,
+                      int64_t batch, uint64_t seed, uint64_t counter, int64_t* n, int64_t* h, int64_t* w,
+                      float* K /*[batch,3,3]*/, float* E /*[batch,4,4]*/, float* rgb_gt /*[batch,3]*/, float* color_bg /*[3]*/,
+                      float* depth, void* stream);
+
 /* ---- ray generation and sample points: renderer.py:38-48 (get_rays) ---- */
 int nerf_raygen(const int64_t* h, const int64_t* w, const float* K /*[N,3,3]*/, const float* E /*[N,4,4]*/,
                 int64_t n_rays, float* rays_o /*[N,3]*/, float* rays_d /*[N,3]*/, void* stream);

@@ -53,6 +53,7 @@ SIGNATURES = {
     'nerf_grid_cfg_init': (_I64, [_G, _I, _I, _I, _I, _F]),
     'nerf_sigma_param_count': (_I64, [_G, _N]),
     'nerf_color_param_count': (_I64, [_N]),
+    'nerf_sample_batch': (_I, [_P, _P, _P, _P, _I64, _I, _I, _I, _I64, C.c_uint64, C.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'nerf_raygen': (_I, [_P, _P, _P, _P, _I64, _P, _P, _P]),
     'nerf_sample_points': (_I, [_P, _P, _P, _I64, _I64, _I, _F, _F, _P, _P, _P, _P]),
     'nerf_contract': (_I, [_P, _I64, _F, _F, _P, _P]),

@@ -558,7 +558,11 @@ static int launch_scatter(const NerfGridCfg* grid, const NerfPointSrc* src, cons
     // small dense levels go through the LDS-privatised kernel (worth it once there are enough points to
     // amortise the flush), everything else through the lane-grouped global-atomic kernel
     ScatterPlan plan = {};
-    for (int i = 0; i < set.count; ++i) {
+    // (largest level first: the chunked levels need whole CUs -- 128 KB of LDS per workgroup -- and starve once the
+    // table update pass fills every CU with its 16 KB workgroups; the smallest level fits beside those)
+    static const int small_order = getenv("NERF_SMALL_ORDER") ? atoi(getenv("NERF_SMALL_ORDER")) : 1;
+    for (int ii = 0; ii < set.count; ++ii) {
+        const int i = small_order ? set.count - 1 - ii : ii;
         const int l = set.level[i], col = col0 + i * F;
         const int64_t floats = (int64_t)grid->entries[l] * F;
         const bool small = !grid->hashed[l] && floats <= (int64_t)kSmallLdsFloats * kSmallMaxChunks && n_points >= 65536;

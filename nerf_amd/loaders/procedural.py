@@ -94,11 +94,44 @@ class DeviceBatchLoader(object):
         return self._ec
 
     def get_random_batch(self, batch_size, device='cuda'):
-        """camera_geometry_loader.py:112-117, sampled on the GPU."""
+        """camera_geometry_loader.py:112-117, sampled on the GPU: one nerf_sample_batch launch for stores that live on
+        the GPU (indices, calibration gather, uint8 -> float ground truth over the batch's random background colour);
+        the torch formulation below serves host-resident stores (the CPU tests of the loader logic)."""
+        if torch.device(self.device).type == 'cuda':
+            return self._sample_batch_hip(batch_size)
         n = torch.randint(0, self.N, (batch_size,), device=self.device, generator=self.generator)
         h = torch.randint(0, self.H, (batch_size,), device=self.device, generator=self.generator)
         w = torch.randint(0, self.W, (batch_size,), device=self.device, generator=self.generator)
         return self.get_custom_batch(n, h, w)
+
+    def _sample_batch_hip(self, B):
+        import ctypes as C
+        from .._lib import check, lib, ptr, stream
+        dev = self.intrinsics.device
+        i64 = lambda: torch.empty(B, dtype=torch.int64, device=dev)
+        n, h, w = i64(), i64(), i64()
+        K = torch.empty(B, 3, 3, device=dev)
+        E = torch.empty(B, 4, 4, device=dev)
+        gt = torch.empty(B, 3, device=dev)
+        bg = torch.empty(3, device=dev)
+        with_depth = self.depths_bool and self.depths is not None
+        depth = torch.empty(B, device=dev) if with_depth else None
+        img = self.images
+        if img is not None and (img.dtype != torch.uint8 or not img.is_contiguous()):
+            raise ValueError('the image store must be a contiguous uint8 tensor [N,H,W,3|4]')
+        # a batch is a pure function of (generator seed, batches drawn since that seed was set): re-seeding the loader's
+        # generator (generator.manual_seed) restarts the sequence, as it does for the torch formulation
+        seed = self.generator.initial_seed()
+        if getattr(self, '_seed_seen', None) != seed:
+            self._seed_seen, self._batch_counter = seed, 0
+        self._batch_counter += 1
+        check(lib().nerf_sample_batch(ptr(img), ptr(self.depths) if with_depth else None, ptr(self.intrinsics),
+                                      ptr(self._centred_extrinsics()), self.N, self.H, self.W,
+                                      int(img.shape[-1]) if img is not None else 4, B,
+                                      C.c_uint64(seed & (2 ** 64 - 1)), C.c_uint64(self._batch_counter),
+                                      ptr(n), ptr(h), ptr(w), ptr(K), ptr(E), ptr(gt), ptr(bg), ptr(depth), stream()),
+              'nerf_sample_batch')
+        return n, h, w, K, E, gt, bg, depth
 
     def get_image_batch(self, image_num, device='cpu'):
         """camera_geometry_loader.py:120-126."""
