@@ -7,7 +7,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libnerf_hip.so')
+# (NERF_HIP_LIB: another build of the same library, for A/B timing of kernel variants on one box)
+LIB_PATH = os.environ.get('NERF_HIP_LIB') or os.path.join(_HERE, 'lib', 'libnerf_hip.so')
 
 NERF_MAX_LEVELS = 32
 

@@ -32,6 +32,7 @@ constexpr int kBinChunkPts = NERF_BIN_CHUNK;   // points per workgroup of the co
 constexpr int kBinThreads = 1024;
 constexpr int kMaxBinsPerLevel = 8192;    // LDS histogram of the count / fill passes: 32 KB
 static_assert(kPartFloats % 4 == 0 && kPartFloats <= 65536, "an item's partition-local offset is stored as uint16");
+static_assert(kMaxBinsPerLevel <= 65536, "the fill pass packs (bin, offset) into one 32-bit word");
 
 struct BinPlan {
     int count;
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_fill_kernel(GridDev g, NerfPo
 // in LDS (counting sort inside the workgroup) and then written out in bin order, so that the items a round adds to one
 // bin leave as one contiguous run per wave instruction instead of as single 2- and 8-byte stores at random times
 // (the plain kernel writes 2.0 GB for 0.63 GB of items -- partially filled lines are evicted and rewritten).
-// Dynamic LDS: cur[nb] | cnt[nb] | start[nb] | wave sums | staged dst (u32), idx (u16), values.
+// Dynamic LDS: cur[nb] | cnt[nb] | start[nb] | wave sums | staged keys (u32: bin, offset), values.
 constexpr int kSortPts = kBinThreads;       // one point per thread and round
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
@@ -224,15 +225,21 @@ __global__ __launch_bounds__(kBinThreads) void bin_fill_sorted_kernel(GridDev g,
     uint32_t* cnt = cur + nb_max;
     uint32_t* start = cnt + nb_max;
     uint32_t* wsum = start + nb_max;                      // kBinThreads / kWave wave totals
-    uint32_t* st_dst = wsum + kBinThreads / kWave;
-    float* st_val = (float*)(st_dst + kItems);
-    uint16_t* st_idx = (uint16_t*)(st_val + kItems * F);
+    // staged items: one packed word (bin << 16 | offset in the partition) and the F values; the scattered LDS stores of
+    // this staging are what the pass is bound by (16 waves share one LDS pipe), so an item is two stores, not four: its
+    // place in global memory is rebuilt at write-out time from the word (cur[bin] + position in the bin's run)
+    uint32_t* st_key = wsum + kBinThreads / kWave;
+    float* st_val = (float*)(st_key + kItems);
     const int slot = blockIdx.y, l = plan.level[slot];
     const uint32_t nb = plan.nbins[slot];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const uint32_t* o = offs + plan.hist_off[slot] + (int64_t)blockIdx.x * nb;
     for (uint32_t i = threadIdx.x; i < nb; i += kBinThreads) { cur[i] = o[i]; cnt[i] = 0u; }
     __syncthreads();
+    // From here on the barriers order LDS traffic only (s_waitcnt lgkmcnt(0) + s_barrier): nothing in global memory is
+    // shared between the threads of this kernel, and a __syncthreads() would make every round wait until its scattered
+    // item stores -- and the next round's point / gradient loads, requested a round ahead -- have completed.
+    auto lds_sync = [] { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_s_barrier(); };
     const LevelP lp = plan_level(g, l);
     const int col = plan.col[slot];
     uint16_t* ii = item_idx + plan.item_off[slot];
@@ -240,18 +247,32 @@ __global__ __launch_bounds__(kBinThreads) void bin_fill_sorted_kernel(GridDev g,
     const int64_t p0 = (int64_t)blockIdx.x * kBinChunkPts;
     const int64_t p1 = p0 + kBinChunkPts < M ? p0 + kBinChunkPts : M;
     const uint32_t per = (nb + kBinThreads - 1) / kBinThreads;     // consecutive bins per thread in the scan
+    // this thread's point of the coming round: position and gradient are requested one round ahead
+    float nx = 0.f, ny = 0.f, nz = 0.f, nd[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) nd[f] = 0.f;
+    auto request = [&](int64_t pp) {
+        if (pp < p1) {
+            const PointIn q = fetch_point(src, pp, false);
+            nx = q.x; ny = q.y; nz = q.z;
+            const float* dp = dfeat + pp * stride + col;
+#pragma unroll
+            for (int f = 0; f < F; ++f) nd[f] = dp[f];
+        }
+    };
+    request(p0 + threadIdx.x);
     for (int64_t base = p0; base < p1; base += kSortPts) {
         const int64_t p = base + threadIdx.x;
         const bool live = p < p1;
         uint32_t bin[8], rank[8], loc[8];
         float val[8][F];
-        if (live) {
-            const PointIn q = fetch_point(src, p, false);
-            const Corners c = level_corners(lp, q.x, q.y, q.z);
-            float d[F];
-            const float* dp = dfeat + p * stride + col;
+        const float qx = nx, qy = ny, qz = nz;
+        float d[F];
 #pragma unroll
-            for (int f = 0; f < F; ++f) d[f] = dp[f];
+        for (int f = 0; f < F; ++f) d[f] = nd[f];
+        request(p + kSortPts);
+        if (live) {
+            const Corners c = level_corners(lp, qx, qy, qz);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const uint32_t fl = c.idx[k] * (uint32_t)F + plan.shift[slot];
@@ -262,43 +283,47 @@ __global__ __launch_bounds__(kBinThreads) void bin_fill_sorted_kernel(GridDev g,
                 for (int f = 0; f < F; ++f) val[k][f] = c.w[k] * d[f];
             }
         }
-        __syncthreads();
+        lds_sync();
         // exclusive scan of cnt[0..nb) -> start
         uint32_t mine = 0;
         for (uint32_t j = 0; j < per; ++j) { const uint32_t b = threadIdx.x * per + j; if (b < nb) mine += cnt[b]; }
         const uint32_t incl = wave_incl_scan(mine, lane);
         if (lane == kWave - 1) wsum[wave] = incl;
-        __syncthreads();
+        lds_sync();
         uint32_t run = incl - mine;
         for (int w = 0; w < wave; ++w) run += wsum[w];
         for (uint32_t j = 0; j < per; ++j) {
             const uint32_t b = threadIdx.x * per + j;
             if (b < nb) { start[b] = run; run += cnt[b]; }
         }
-        __syncthreads();
+        lds_sync();
         if (live) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const uint32_t s_ = start[bin[k]] + rank[k];
-                st_dst[s_] = cur[bin[k]] + rank[k];
-                st_idx[s_] = (uint16_t)loc[k];
+                st_key[s_] = (bin[k] << 16) | loc[k];
+                if (F == 2) { f32x2 t; t.x = val[k][0]; t.y = val[k][F - 1]; *(f32x2*)(st_val + s_ * 2) = t; }
+                else {
 #pragma unroll
-                for (int f = 0; f < F; ++f) st_val[s_ * F + f] = val[k][f];
+                    for (int f = 0; f < F; ++f) st_val[s_ * F + f] = val[k][f];
+                }
             }
         }
-        __syncthreads();
+        lds_sync();
         const int64_t n_live = (p1 - base < kSortPts ? p1 - base : kSortPts) * 8;
         for (int s_ = threadIdx.x; s_ < n_live; s_ += kBinThreads) {
-            const uint32_t dst = st_dst[s_];
-            ii[dst] = st_idx[s_];
+            const uint32_t key = st_key[s_], b_ = key >> 16;
+            const uint32_t dst = cur[b_] + ((uint32_t)s_ - start[b_]);
+            ii[dst] = (uint16_t)(key & 0xFFFFu);
             if (F == 2) *(f32x2*)(iv + (int64_t)dst * 2) = *(const f32x2*)(st_val + s_ * 2);
             else {
 #pragma unroll
                 for (int f = 0; f < F; ++f) iv[(int64_t)dst * F + f] = st_val[s_ * F + f];
             }
         }
+        lds_sync();          // the write-out above reads cur[] and start[]
         for (uint32_t i = threadIdx.x; i < nb; i += kBinThreads) { cur[i] += cnt[i]; cnt[i] = 0u; }
-        __syncthreads();
+        lds_sync();
     }
 }
 
@@ -313,8 +338,8 @@ __global__ __launch_bounds__(kBinThreads) void bin_fill_sorted_kernel(GridDev g,
 // once, measured SLOWER (2.00 vs 1.92 ms on one box): the stream wants consecutive blocks on consecutive addresses.
 // (Measured on one box, update pass alone: quarters 1.86 ms; halves 1.96; eighths 1.89; quarters with every item's
 // values requested together with its index, before the quarter test, 1.90.)
-constexpr int kSubs = 4;
-constexpr int kSubFloats = kPartFloats / kSubs;
+constexpr int kSubFloats = 4096;
+constexpr int kSubs = kPartFloats / kSubFloats;
 constexpr int kSplitThreads = 256;
 
 template <int F>
@@ -367,32 +392,52 @@ __global__ __launch_bounds__(kSplitThreads) void table_update_kernel(GridDev g, 
     if (n_items) { b0 = bs[bin] < n_items ? bs[bin] : n_items; b1 = bs[bin + 1] < n_items ? bs[bin + 1] : n_items; }
     const int64_t i0 = plan.item_off[slot] + b0, i1 = plan.item_off[slot] + (b1 > b0 ? b1 : b0);
     const int lo = (int)sub * kSubFloats;
-    constexpr int U = 4;                // four items per thread and round, their loads issued together
-    int64_t i = i0 + tid;
-    for (; i + (U - 1) * T < i1; i += U * T) {
-        int li[U];
+    auto add_item = [&](int64_t i, int idx) {
+        const int li = idx - lo;
+        if ((unsigned)li <= (unsigned)(kSubFloats - F)) {
+            if (F == 2) {
+                const f32x2 t = *(const f32x2*)(item_val + i * 2);
+                atomicAdd(acc + li, t.x);
+                atomicAdd(acc + li + 1, t.y);
+            } else {
 #pragma unroll
-        for (int u = 0; u < U; ++u) li[u] = (int)item_idx[i + u * T] - lo;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if ((unsigned)li[u] <= (unsigned)(kSubFloats - F)) {
-                if (F == 2) {
-                    const f32x2 t = *(const f32x2*)(item_val + (i + u * T) * 2);
-                    atomicAdd(acc + li[u], t.x);
-                    atomicAdd(acc + li[u] + 1, t.y);
-                } else {
-#pragma unroll
-                    for (int f = 0; f < F; ++f) atomicAdd(acc + li[u] + f, item_val[(i + u * T) * F + f]);
-                }
+                for (int f = 0; f < F; ++f) atomicAdd(acc + li + f, item_val[i * F + f]);
             }
         }
-    }
-    for (; i < i1; i += T) {
-        const int li = (int)item_idx[i] - lo;
-        if ((unsigned)li <= (unsigned)(kSubFloats - F)) {
+    };
+    // the bin's indices are scanned eight at a time (16-byte loads, two per thread in flight); the values of the few items
+    // that fall into this workgroup's share of the partition are fetched afterwards
+    const int64_t a0 = (i0 + 7) & ~(int64_t)7, a1 = i1 & ~(int64_t)7;
+    if (a0 < a1) {
+        for (int64_t i = i0 + tid; i < a0; i += T) add_item(i, item_idx[i]);
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4* iv4 = (const u32x4*)item_idx;
+        int64_t gidx = (a0 >> 3) + tid;
+        const int64_t gend = a1 >> 3;
+        for (; gidx + T < gend; gidx += 2 * T) {
+            const u32x4 va = iv4[gidx], vb = iv4[gidx + T];
 #pragma unroll
-            for (int f = 0; f < F; ++f) atomicAdd(acc + li + f, item_val[i * F + f]);
+            for (int e = 0; e < 4; ++e) {
+                add_item(gidx * 8 + 2 * e, (int)(va[e] & 0xFFFFu));
+                add_item(gidx * 8 + 2 * e + 1, (int)(va[e] >> 16));
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                add_item((gidx + T) * 8 + 2 * e, (int)(vb[e] & 0xFFFFu));
+                add_item((gidx + T) * 8 + 2 * e + 1, (int)(vb[e] >> 16));
+            }
         }
+        for (; gidx < gend; gidx += T) {
+            const u32x4 va = iv4[gidx];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                add_item(gidx * 8 + 2 * e, (int)(va[e] & 0xFFFFu));
+                add_item(gidx * 8 + 2 * e + 1, (int)(va[e] >> 16));
+            }
+        }
+        for (int64_t i = a1 + tid; i < i1; i += T) add_item(i, item_idx[i]);
+    } else {
+        for (int64_t i = i0 + tid; i < i1; i += T) add_item(i, item_idx[i]);
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_s_barrier();
@@ -497,7 +542,7 @@ extern "C" int nerf_table_bin_levels(const NerfGridCfg* grid, const NerfPointSrc
     for (int i = 0; i < plan.count; ++i) nb_max = plan.nbins[i] > nb_max ? plan.nbins[i] : nb_max;
     nb_max = (nb_max + 3u) & ~3u;            // keeps the staged arrays behind the counters 16-byte aligned
     // LDS of the sorted fill pass: 3 arrays of nb_max counters, 16 wave sums, 8 * kSortPts staged items
-    const int sorted_lds = (int)((3 * (size_t)nb_max + kBinThreads / kWave) * 4 + (size_t)8 * kSortPts * (4 + 4 * F + 2));
+    const int sorted_lds = (int)((3 * (size_t)nb_max + kBinThreads / kWave) * 4 + (size_t)8 * kSortPts * (4 + 4 * F));
     const bool sorted = sorted_lds <= 150 * 1024 && !getenv("NERF_BIN_FILL_PLAIN");
 #define BIN_PASSES(FF)                                                                                                 \
     do {                                                                                                               \
