@@ -7,7 +7,7 @@ points with sigma > thresh.  Differences, on purpose:
 * under torch.distributed each rank takes a contiguous slab of the voxel index range and the
   variable-length results are all_gathered once;
 * the open3d wrapper ``generate_dense_pointcloud`` is out of scope (open3d is not part of the hot path).
-The field evaluation itself is ``NeRFNetwork.forward`` -> nerf_field_fwd (HIP)."""
+The field evaluation itself is ``NeRFNetwork.field_nograd`` -> nerf_field_fwd (HIP) without the feature rows."""
 import torch
 
 from . import parallel
@@ -75,7 +75,10 @@ class ExtractDenseGeometry():
             if xyz.shape[0] > 0:
                 dirs = dir_z[None].expand(xyz.shape[0], 3).contiguous()
                 n_i = torch.zeros(xyz.shape[0], dtype=torch.int64, device=dev)
-                sigmas, rgbs, _ = self.model(xyz, dirs, n_i, self.outer_bound)
+                # field_nograd: no autograd node and no x_hashtable rows (160 B/point the reference's forward
+                # returns at :88 and extraction discards)
+                sigmas, rgbs = self.model.field_nograd(dict(outer_bound=self.outer_bound, x=xyz, d=dirs, n=n_i,
+                                                            n_points=xyz.shape[0]))
                 sel = sigmas > self.thresh
                 points.append(xyz[sel])
                 colors.append(rgbs[sel])
