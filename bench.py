@@ -98,9 +98,8 @@ def train_step(model, renderer, loader, opt, n_rays, it, world):
     loss.backward()
     opt.skip_flag = loss.nonfinite_flag        # Trainer.train_epoch's non-finite guard (device side, no sync)
     if world > 1:
-        parallel.all_reduce_sum_(opt.skip_flag)
         skip = [opt._table_param] if opt.table_reduced_by_pipeline() else []
-        parallel.all_reduce_grads([p for g in opt.param_groups for p in g['params']], skip=skip)
+        parallel.all_reduce_grads([p for g in opt.param_groups for p in g['params']], skip=skip, flags=[opt.skip_flag])
         opt.grad_scale = 1.0 / world
     opt.step()
     return loss

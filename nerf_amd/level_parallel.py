@@ -106,6 +106,23 @@ def assign_levels(cfg, world):
     return owner
 
 
+def _slice_rows(kw, ra, rb, unit):
+    """make_point_src kwargs restricted to rays [ra, rb) (ray sources) or points [ra, rb) (point sources)."""
+    out = dict(kw)
+    if kw.get('x') is not None:
+        out.update(x=kw['x'][ra:rb], n_points=rb - ra)
+        for k in ('d', 'n'):
+            if kw.get(k) is not None:
+                out[k] = kw[k][ra:rb]
+        return out
+    zs = kw.get('z_stride', 0)
+    out.update(rays_o=kw['rays_o'][ra:rb], rays_d=kw['rays_d'][ra:rb], z=kw['z'] if zs == 0 else kw['z'][ra:rb],
+               n_points=(rb - ra) * unit)
+    if kw.get('n') is not None:
+        out['n'] = kw['n'][ra:rb]
+    return out
+
+
 def _level_set(levels):
     s = NerfLevelSet()
     s.count = len(levels)
@@ -135,6 +152,7 @@ class LevelSharding(object):
             inv[c] = i
         self.inv = torch.tensor(inv, device=device, dtype=torch.int64)
         self._colmaps = {}
+        self._group_perm = {}
         self.force = False      # run the exchange code even in a world of one rank (exercises the RCCL calls on one GPU)
         self.dirty = False      # True once an optimizer step made the non-owned levels of the local table stale
 
@@ -176,6 +194,118 @@ class LevelSharding(object):
             self._colmaps[m_local] = cm
         return cm
 
+    # ---- ray groups: the exchanges of consecutive groups overlap the compute of their neighbours ------------
+    def n_groups(self, n_points):
+        """How many ray groups a batch of `n_points` local sample points is cut into.  One all-to-all per group and
+        pass: while group g is on the wire the owner encodes group g+1 and the MLPs run on group g-1, so only the
+        first encode and the last MLP of a pass are not covered (the case that matters is a world of two ranks, where
+        everything a rank exchanges crosses ONE xGMI link).  NERF_SHARD_GROUPS overrides."""
+        env = os.environ.get('NERF_SHARD_GROUPS')
+        if env:     # a count (equal groups) or comma-separated fractions of the rays ("0.25,0.5,0.25")
+            return [float(f) for f in env.split(',')] if ',' in env else max(1, int(env))
+        if self.world <= 1 or n_points < 131072:
+            return 1
+        # measured with the modelled wire (tools/shard_step_emulate.py, profiles/r02c_shard_wire_*.log): two groups win
+        # at worlds 2 and 4 (5.78 -> 5.59 and 4.98 -> 4.81 ms), at world 8 the per-link volume is too small to matter,
+        # and four groups lose more to the smaller launches than they hide
+        return 2 if self.world <= 4 else 1
+
+    def plan(self, kw, groups=None):
+        """Gather the point source of every rank (one all-gather, as gather_src) and cut it into ray groups.
+        The gathered rays are kept GROUP-major ([group][rank][ray]) so that the points of all ranks of one group are
+        one contiguous source, and so are the points of all groups: the d(features) matrix the owners receive in the
+        backward pass has its rows in exactly this order."""
+        rays = kw.get('x') is None
+        unit = int(kw['n_samples']) if rays else 1
+        M = int(kw['n_points'])
+        rows = M // unit
+        groups = groups or self.n_groups(M)
+        W = self.world
+        if isinstance(groups, (list, tuple)):
+            edges, acc = [0], 0.0
+            for f in groups[:-1]:
+                acc += f / float(sum(groups))
+                edges.append(min(rows, max(edges[-1], int(round(acc * rows)))))
+            edges.append(rows)
+            cuts = [(a, b) for a, b in zip(edges[:-1], edges[1:]) if b > a] or [(0, rows)]
+        else:
+            G = max(1, min(int(groups), max(rows, 1)))
+            cuts = [parallel.shard_range(rows, g, G) for g in range(G)]
+        G = len(cuts)
+        whole = self.gather_src(kw) if G == 1 else self._gather_group_major(kw, cuts, rows)
+        out = []
+        for (ra, rb) in cuts:
+            grp = {'ra': ra, 'rb': rb, 'a': ra * unit, 'b': rb * unit, 'm': (rb - ra) * unit}
+            grp['kw_local'] = _slice_rows(kw, ra, rb, unit)
+            grp['kw_all'] = whole if G == 1 else _slice_rows(whole, W * ra, W * rb, unit)
+            out.append(grp)
+        return {'groups': out, 'kw_all': whole, 'm_local': M, 'unit': unit}
+
+    def _gather_group_major(self, kw, cuts, rows):
+        W = self.world
+        key = (rows, tuple(cuts), W)
+        perm = self._group_perm.get(key)
+        if perm is None:
+            idx = [q * rows + i for (ra, rb) in cuts for q in range(W) for i in range(ra, rb)]
+            perm = self._group_perm[key] = torch.tensor(idx, dtype=torch.int64, device=self.perm.device)
+        out = dict(outer_bound=kw['outer_bound'], inner_bound=kw.get('inner_bound', 0.0))
+        if kw.get('x') is not None:
+            x = parallel.all_gather_rows(kw['x']).index_select(0, perm.to(kw['x'].device))
+            out.update(x=x, n_points=x.shape[0])
+            return out
+        ro, rd = kw['rays_o'], kw['rays_d']
+        S, zs = kw['n_samples'], kw.get('z_stride', 0)
+        perm = perm.to(ro.device)
+        if zs == 0:
+            g = parallel.all_gather_rows(torch.cat([ro, rd], 1)).index_select(0, perm)
+            z = kw['z']
+        else:
+            g = parallel.all_gather_rows(torch.cat([ro, rd, kw['z'].view(ro.shape[0], zs)], 1)).index_select(0, perm)
+            z = g[:, 6:].contiguous()
+        out.update(rays_o=g[:, 0:3].contiguous(), rays_d=g[:, 3:6].contiguous(), z=z, z_stride=zs, n_samples=S,
+                   n_points=W * kw['n_points'])
+        return out
+
+    def encode_exchange_groups(self, table, plan, xh):
+        """Generator over the plan's groups, in order: yields a group once rows [a, b) of `xh` hold its feature rows.
+        Schedule on the compute stream: E0 | E1 F0 | E2 F1 | ... | F(G-1), where E = encode my levels for the
+        group (remote points, start the all-to-all, own points) and F = wait + shuffle into xh; the caller's MLP on
+        the yielded rows follows F, so the all-to-all of group g runs under E(g+1) and the MLP of group g-1."""
+        pend = None
+        for grp in plan['groups']:
+            st = self._encode_start(table, grp['kw_all'], grp['m'])
+            if pend is not None:
+                self._encode_finish(pend[0], pend[1], xh)
+                yield pend[1]
+            pend = (st, grp)
+        if pend is not None:
+            self._encode_finish(pend[0], pend[1], xh)
+            yield pend[1]
+
+    def _encode_start(self, table, src_all, m_local):
+        W, r, wm = self.world, self.rank, self.width[self.rank]
+        dev = table.device
+        if os.environ.get('NERF_TEST_SHARD_FAIL'):      # rehearsal hook for bench.py's replicated-table fallback
+            raise RuntimeError('injected failure (NERF_TEST_SHARD_FAIL)')
+        send = torch.empty(W * m_local * wm, device=dev, dtype=torch.float32)
+        recv = torch.empty(m_local * sum(self.width), device=dev, dtype=torch.float32)
+        send_blocks = self._blocks(send, m_local, [wm] * W)
+        recv_blocks = self._blocks(recv, m_local, self.width)
+        if wm:
+            for (a, b) in ((0, r), (r + 1, W)):
+                if b > a:
+                    self._encode(table, self._sub_src(src_all, a, b, m_local), send_blocks[a], wm)
+        work = parallel.all_to_all_blocks(recv_blocks, send_blocks, async_op=True)
+        if wm:
+            self._encode(table, self._sub_src(src_all, r, r + 1, m_local), recv_blocks[r], wm)
+        return (work, send, recv, m_local)
+
+    def _encode_finish(self, st, grp, xh):
+        work, _send, recv, m_local = st
+        if work is not None:
+            work.wait()
+        self.assemble(recv, m_local, out=xh[grp['a']:grp['b']])
+
     # ---- helpers ---------------------------------------------------------------------------
     def _sub_src(self, src_all, a, b, m_local):
         """make_point_src kwargs for the points of ranks [a, b) out of the gathered source."""
@@ -205,39 +335,29 @@ class LevelSharding(object):
 
     # ---- forward: encode my levels for everybody, all-to-all, assemble [M, L*F] -------------
     def encode_exchange(self, table, src_all, m_local):
-        """x_hashtable [m_local, L*F] of this rank's points.  Order of work: encode my levels for the points of the
-        OTHER ranks, start the all-to-all, encode them for my own points (straight into my block of the receive
-        buffer) while the exchange is in flight, wait, one shuffle pass into level-major rows."""
-        W, r, wm = self.world, self.rank, self.width[self.rank]
-        dev = table.device
-        if os.environ.get('NERF_TEST_SHARD_FAIL'):      # rehearsal hook for bench.py's replicated-table fallback
-            raise RuntimeError('injected failure (NERF_TEST_SHARD_FAIL)')
-        send = torch.empty(W * m_local * wm, device=dev, dtype=torch.float32)
-        recv = torch.empty(m_local * sum(self.width), device=dev, dtype=torch.float32)
-        send_blocks = self._blocks(send, m_local, [wm] * W)
-        recv_blocks = self._blocks(recv, m_local, self.width)
-        if wm:
-            for (a, b) in ((0, r), (r + 1, W)):
-                if b > a:
-                    self._encode(table, self._sub_src(src_all, a, b, m_local), send_blocks[a], wm)
-        work = parallel.all_to_all_blocks(recv_blocks, send_blocks, async_op=True)
-        if wm:
-            self._encode(table, self._sub_src(src_all, r, r + 1, m_local), recv_blocks[r], wm)
+        """x_hashtable [m_local, L*F] of this rank's points (one group).  Order of work: encode my levels for the
+        points of the OTHER ranks, start the all-to-all, encode them for my own points (straight into my block of the
+        receive buffer) while the exchange is in flight, wait, one shuffle pass into level-major rows."""
+        work, _send, recv, _m = self._encode_start(table, src_all, m_local)
         if work is not None:
             work.wait()
         return self.assemble(recv, m_local)
 
-    def assemble(self, recv, m_local):
-        """Owner-major blocks of the receive buffer -> [m_local, L*F] level-major rows."""
+    def assemble(self, recv, m_local, out=None):
+        """Owner-major blocks of the receive buffer -> [m_local, L*F] level-major rows (into `out` when given)."""
         if recv.is_cuda:
             LF = self.cfg.n_levels * self.F
-            xh = torch.empty(m_local, LF, device=recv.device, dtype=torch.float32)
+            xh = out if out is not None else torch.empty(m_local, LF, device=recv.device, dtype=torch.float32)
             check(lib().nerf_feature_shuffle(ptr(recv), ptr(xh), m_local, LF, C.byref(self.col_map(m_local)), 0, stream()),
                   'nerf_feature_shuffle')
             return xh
         chunks = [blk.view(m_local, w) for blk, w in zip(self._blocks(recv, m_local, self.width), self.width)]
         xh = torch.cat(chunks, 1)       # host tensors (the CPU tests of the exchange logic)
-        return xh if self.identity else xh.index_select(1, self.inv)
+        xh = xh if self.identity else xh.index_select(1, self.inv)
+        if out is not None:
+            out.copy_(xh)
+            return out
+        return xh
 
     def exchange_features(self, send, m_local):
         """send: flat [world, m_local, width_mine] (my levels, everybody's points, own block included) ->
@@ -327,6 +447,84 @@ class LevelSharding(object):
             pipe.keep += [recv, src_all]
             pipe.bin(self.cfg, make_point_src(**self._sub_src(src_all, 0, W, M)), recv, wm,
                      {l: slot[l] * self.F for l in binned}, dtable, keepalive=src_all)
+
+    def dfeat_exchange_start(self, plan, grp, dfeat_rows, state=None, dtable=None, pipe=None):
+        """Backward of one ray group: send the gradient columns of every owner's levels for this group's points
+        (asynchronously; the caller's backward of the next group runs meanwhile).  `state` carries the receive matrix
+        of the whole plan, [world * m_local, width_mine] with its rows in the plan's group-major point order.
+        With `dtable`, the levels that keep the atomic scatter take the rows of my OWN points of this group now, and the
+        rows the PREVIOUS group's exchange has brought: both run under this group's transfer."""
+        W, r, wm = self.world, self.rank, self.width[self.rank]
+        M, m = plan['m_local'], grp['m']
+        if state is None:
+            state = {'recv': torch.empty(W * M * wm, device=dfeat_rows.device, dtype=torch.float32), 'works': [], 'keep': [],
+                     'scattered': 0, 'begun': False}
+        if pipe is not None and dtable is not None and not state['begun']:
+            pipe.begin(dtable)
+            state['begun'] = True
+        send = self.split(dfeat_rows)
+        recv_g = state['recv'][W * grp['a'] * wm:W * grp['b'] * wm]
+        send_blocks, recv_blocks = self._blocks(send, m, self.width), self._blocks(recv_g, m, [wm] * W)
+        work = parallel.all_to_all_blocks(recv_blocks, send_blocks, async_op=True)
+        if wm:
+            recv_blocks[r].copy_(send_blocks[r])        # my own points' rows never travel
+        state['works'].append((work, grp, recv_blocks))
+        state['keep'].append(send)
+        if wm and dtable is not None:
+            binned = list(pipe.binned_levels) if pipe is not None else []
+            self._scatter_rows(grp['kw_all'], r, r + 1, m, ptr(send_blocks[r]), binned, dtable)
+            self._scatter_arrived(state, len(state['works']) - 1, binned, dtable)
+        return state
+
+    def _scatter_rows(self, src_all, qa, qb, m, base_ptr, binned, dtable):
+        """Atomic scatter of the non-binned levels of mine for the points of ranks [qa, qb) of one group; `base_ptr`:
+        first row of rank qa's block in a [*, width_mine] gradient matrix."""
+        early = [l for l in self.mine if l not in binned]
+        if not early or qb <= qa:
+            return
+        kw = self._sub_src(src_all, qa, qb, m)
+        if early == self.mine[:len(early)]:         # a prefix of my columns: one call for all of them
+            self._scatter(kw, _level_set(early), base_ptr, self.width[self.rank], dtable)
+            return
+        slot = {l: i for i, l in enumerate(self.mine)}
+        for l in early:
+            self._scatter(kw, _level_set([l]), base_ptr + 4 * slot[l] * self.F, self.width[self.rank], dtable)
+
+    def _scatter_arrived(self, state, upto, binned, dtable):
+        """Scatter the remote rows of the groups [state['scattered'], upto) -- their exchanges are waited for."""
+        W, r = self.world, self.rank
+        while state['scattered'] < upto:
+            work, grp, recv_blocks = state['works'][state['scattered']]
+            if work is not None:
+                work.wait()
+            for (qa, qb) in ((0, r), (r + 1, W)):
+                if qb > qa:
+                    self._scatter_rows(grp['kw_all'], qa, qb, grp['m'], ptr(recv_blocks[qa]), binned, dtable)
+            state['scattered'] += 1
+
+    def dfeat_exchange_finish(self, plan, state, dtable, pipe=None):
+        """Wait for the remaining all-to-alls and scatter what they brought; then the levels of the binned update are
+        sorted into table partitions (TablePipeline.bin) from the gradient rows of the points of ALL ranks."""
+        wm = self.width[self.rank]
+        binned = list(pipe.binned_levels) if pipe is not None else []
+        if wm:
+            self._scatter_arrived(state, len(state['works']), binned, dtable)
+        else:
+            for work, _g, _b in state['works']:
+                if work is not None:
+                    work.wait()
+            return
+        if pipe is None:
+            return
+        for (l0, cnt) in pipe.groups:
+            pipe.level_done(l0, cnt)
+        recv, src_all = state['recv'], plan['kw_all']
+        pipe.keep += [recv, src_all, state['keep']]
+        if binned:
+            from .nets import make_point_src
+            slot = {l: i for i, l in enumerate(self.mine)}
+            pipe.bin(self.cfg, make_point_src(**src_all), recv, wm, {l: slot[l] * self.F for l in binned}, dtable,
+                     keepalive=src_all)
 
     # ---- table consistency ---------------------------------------------------------------
     def level_slice(self, l):

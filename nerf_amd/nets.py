@@ -302,15 +302,20 @@ class _ShardedFieldFn(torch.autograd.Function):
         src = make_point_src(**src_kwargs)
         M = src.n_points
         dev = table.device
-        src_all = sh.gather_src(src_kwargs)
-        xh = sh.encode_exchange(table, src_all, M)
+        plan = sh.plan(src_kwargs)
         sigma = torch.empty(M, device=dev, dtype=torch.float32)
         rgb = torch.empty(M, 3, device=dev, dtype=torch.float32)
         xyz = torch.empty(M, 3, device=dev, dtype=torch.float32) if want_xyz else None
-        check(lib().nerf_field_from_features(C.byref(net.encoder.cfg), C.byref(net.net_cfg), ptr(sigma_w), ptr(color_w),
-                                             ptr(latent), net.N, C.byref(src), ptr(xh), ptr(sigma), ptr(rgb), ptr(xyz),
-                                             stream()), 'nerf_field_from_features')
-        ctx.net, ctx.src_kwargs, ctx.src_all = net, src_kwargs, src_all
+        xh = torch.empty(M, net.encoder.n_output_dims, device=dev, dtype=torch.float32)
+        # group by group: the MLPs of a group run while the next group's features are on the wire
+        for grp in sh.encode_exchange_groups(table, plan, xh):
+            a, b = grp['a'], grp['b']
+            sub = src if len(plan['groups']) == 1 else make_point_src(**grp['kw_local'])
+            check(lib().nerf_field_from_features(C.byref(net.encoder.cfg), C.byref(net.net_cfg), ptr(sigma_w), ptr(color_w),
+                                                 ptr(latent), net.N, C.byref(sub), ptr(xh[a:b]), ptr(sigma[a:b]),
+                                                 ptr(rgb[a:b]), ptr(xyz[a:b]) if xyz is not None else None,
+                                                 stream()), 'nerf_field_from_features')
+        ctx.net, ctx.src_kwargs, ctx.plan = net, src_kwargs, plan
         ctx.save_for_backward(table, sigma_w, color_w, latent, xh)
         ctx.mark_non_differentiable(xh)
         ctx.set_materialize_grads(False)
@@ -337,10 +342,25 @@ class _ShardedFieldFn(torch.autograd.Function):
             dtable, dsw, dcw = torch.zeros_like(table), torch.zeros_like(sigma_w), torch.zeros_like(color_w)
             dlat = torch.zeros_like(latent) if latent is not None else None
         dfeat = torch.empty_like(xh)
-        check(lib().nerf_field_bwd(C.byref(net.encoder.cfg), C.byref(net.net_cfg), None, ptr(sigma_w), ptr(color_w),
-                                   ptr(latent), net.N, C.byref(src), ptr(xh), ptr(f32(dsigma)), ptr(f32(drgb)),
-                                   ptr(dfeat), None, ptr(dsw), ptr(dcw), ptr(dlat), stream()), 'nerf_field_bwd')
-        sh.exchange_scatter(dfeat, ctx.src_all, dtable, net.table_pipeline)
+        dsigma, drgb = f32(dsigma), f32(drgb)
+        plan = ctx.plan
+        if len(plan['groups']) == 1:
+            check(lib().nerf_field_bwd(C.byref(net.encoder.cfg), C.byref(net.net_cfg), None, ptr(sigma_w), ptr(color_w),
+                                       ptr(latent), net.N, C.byref(src), ptr(xh), ptr(dsigma), ptr(drgb),
+                                       ptr(dfeat), None, ptr(dsw), ptr(dcw), ptr(dlat), stream()), 'nerf_field_bwd')
+            sh.exchange_scatter(dfeat, plan['kw_all'], dtable, net.table_pipeline)
+        else:
+            # group by group: d(features) of a group travels to the level owners under the backward of the next one
+            state = None
+            for grp in plan['groups']:
+                a, b = grp['a'], grp['b']
+                sub = make_point_src(**grp['kw_local'])
+                check(lib().nerf_field_bwd(C.byref(net.encoder.cfg), C.byref(net.net_cfg), None, ptr(sigma_w), ptr(color_w),
+                                           ptr(latent), net.N, C.byref(sub), ptr(xh[a:b]), ptr(dsigma[a:b]), ptr(drgb[a:b]),
+                                           ptr(dfeat[a:b]), None, ptr(dsw), ptr(dcw), ptr(dlat), stream()),
+                      'nerf_field_bwd')
+                state = sh.dfeat_exchange_start(plan, grp, dfeat[a:b], state, dtable, net.table_pipeline)
+            sh.dfeat_exchange_finish(plan, state, dtable, net.table_pipeline)
         if direct:
             return None, None, None, None, None, None, None
         return dtable, dsw, dcw, dlat, None, None, None
@@ -520,10 +540,15 @@ class NeRFNetwork(nn.Module):
             return self.density_src(make_point_src(**src_kwargs), want_features)
         sh = self.level_sharding
         M = int(src_kwargs['n_points'])
-        xh = sh.encode_exchange(self.encoder.params, sh.gather_src(src_kwargs), M)
-        sigma = torch.empty(M, device=xh.device, dtype=torch.float32)
-        check(lib().nerf_density_from_features(C.byref(self.encoder.cfg), C.byref(self.net_cfg), ptr(self.sigma_net.params),
-                                               ptr(xh), M, ptr(sigma), stream()), 'nerf_density_from_features')
+        plan = sh.plan(src_kwargs)
+        dev = self.encoder.params.device
+        xh = torch.empty(M, self.encoder.n_output_dims, device=dev, dtype=torch.float32)
+        sigma = torch.empty(M, device=dev, dtype=torch.float32)
+        for grp in sh.encode_exchange_groups(self.encoder.params, plan, xh):
+            a, b = grp['a'], grp['b']
+            check(lib().nerf_density_from_features(C.byref(self.encoder.cfg), C.byref(self.net_cfg), ptr(self.sigma_net.params),
+                                                   ptr(xh[a:b]), b - a, ptr(sigma[a:b]), stream()),
+                  'nerf_density_from_features')
         return sigma, (xh if want_features else None)
 
     @torch.no_grad()

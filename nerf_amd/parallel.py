@@ -77,9 +77,11 @@ def all_reduce_sum_(t, async_op=False):
     return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op)
 
 
-def all_reduce_grads(params, async_op=False, skip=()):
+def all_reduce_grads(params, async_op=False, skip=(), flags=()):
     """SUM-all-reduce the .grad of every parameter (largest first so the big transfer starts early).
     `skip`: parameters whose gradient is reduced elsewhere (the pipelined hash table).
+    `flags`: small counters (the non-finite flag of the loss) that ride in the same collective as the small
+    gradients -- a collective of their own would cost one more latency per step; values must be exact in fp32.
     Returns the list of work handles when async_op."""
     if not dist.is_initialized():
         return []
@@ -88,15 +90,22 @@ def all_reduce_grads(params, async_op=False, skip=()):
     todo = sorted((p for p in params if p is not None and p.grad is not None and id(p) not in skip_ids),
                   key=lambda t: -t.numel())
     small = [p for p in todo if p.numel() <= (1 << 20)]
-    if len(small) > 1 and not async_op:
+    flags = [f for f in flags if f is not None]
+    if len(small) + len(flags) > 1 and not async_op:
         # the MLP / latent gradients are a few KB each: one collective for all of them
-        flat = torch.cat([p.grad.reshape(-1) for p in small])
+        flat = torch.cat([p.grad.reshape(-1) for p in small] + [f.reshape(-1).to(torch.float32) for f in flags])
         all_reduce_sum_(flat)
         o = 0
         for p in small:
             p.grad.copy_(flat[o:o + p.numel()].view_as(p.grad))
             o += p.numel()
+        for f in flags:
+            f.copy_(flat[o:o + f.numel()].view_as(f))
+            o += f.numel()
         todo = [p for p in todo if p.numel() > (1 << 20)]
+        flags = []
+    for f in flags:
+        all_reduce_sum_(f)
     for p in todo:
         h = all_reduce_sum_(p.grad, async_op=async_op)
         if async_op and h is not None:

@@ -63,7 +63,9 @@ def _dp_worker(rank, world, port, q):
     mine = tuple(t[a:b] if (torch.is_tensor(t) and t.dim() > 0 and t.shape[0] == 32) else t for t in full)
     _grads(net, R, mine)
     params = list(net.parameters())
-    parallel.all_reduce_grads(params)
+    flag = torch.tensor([float(rank)], dtype=torch.float64)    # the non-finite flag rides in the same collective
+    parallel.all_reduce_grads(params, flags=[flag])
+    assert float(flag) == sum(range(world)) and flag.dtype == torch.float64
     out = [p.grad / world for p in params]                 # the 1/world factor the fused Adam applies
     if rank == 0:
         q.put([o.numpy() for o in out])
@@ -180,7 +182,32 @@ def _exchange_worker(rank, world, port, q):
     sh.dirty = True
     sh.sync_table(table)
     ok_sync = all(bool((table[sh.level_slice(l)[0]:sh.level_slice(l)[1]] == sh.owner[l]).all()) for l in range(L))
-    q.put((rank, ok_fwd, ok_bwd, ok_sync, sorted(sh.mine)))
+    # ray groups (LevelSharding.plan): 5 rays x 3 samples per rank in groups of 3 + 2 rays; the gathered source and the
+    # d(features) matrix the owners receive are group-major ([group][rank][ray])
+    R, S = 5, 3
+    ray = lambda r, i: 100.0 * r + i
+    ro = torch.tensor([[ray(rank, i), 0.0, 1.0] for i in range(R)])
+    z = torch.tensor([[ray(rank, i) + 0.1 * k for k in range(S)] for i in range(R)])
+    kw = dict(outer_bound=2.0, inner_bound=1.0, rays_o=ro, rays_d=-ro, z=z, z_stride=S, n_samples=S, n_points=R * S,
+              n=torch.arange(R))
+    plan = sh.plan(kw, groups=2)
+    order = [(r, i) for (ra, rb) in ((0, 3), (3, 5)) for r in range(world) for i in range(ra, rb)]
+    want_o = torch.tensor([ray(r, i) for r, i in order])
+    ok_plan = (torch.equal(plan['kw_all']['rays_o'][:, 0], want_o) and torch.equal(plan['kw_all']['z'][:, 0], want_o)
+               and plan['kw_all']['n_points'] == world * R * S
+               and [(g['a'], g['b']) for g in plan['groups']] == [(0, 9), (9, 15)]
+               and torch.equal(plan['groups'][1]['kw_all']['rays_o'][:, 0], want_o[world * 3:])
+               and torch.equal(plan['groups'][1]['kw_local']['n'], torch.arange(3, 5))
+               and torch.equal(plan['groups'][1]['kw_local']['z'], z[3:5]))
+    # backward data movement of the groups: value = 1000 rank + 100 point + 10 level + f at point p = ray * S + k
+    dfeat = torch.tensor([[val(rank, p, l, f) for l in range(L) for f in range(F)] for p in range(R * S)])
+    state = None
+    for grp in plan['groups']:
+        state = sh.dfeat_exchange_start(plan, grp, dfeat[grp['a']:grp['b']].contiguous(), state)
+    pts = [(r, i * S + k) for r, i in order for k in range(S)]
+    want_recv = torch.tensor([[val(r, p, l, f) for l in sh.mine for f in range(F)] for r, p in pts])
+    ok_plan = ok_plan and torch.equal(state['recv'].view(world * R * S, -1), want_recv)
+    q.put((rank, ok_fwd, ok_bwd and ok_plan, ok_sync, sorted(sh.mine)))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -70,8 +70,9 @@ def _train(rank, world, log2_T=15):
     return [p.detach().cpu() for p in (net.encoder.params, net.sigma_net.params, net.color_net.params, net.latent_emb)]
 
 
-def _worker(rank, world, port, q, mode, log2_T):
+def _worker(rank, world, port, q, mode, log2_T, groups):
     os.environ['NERF_TABLE_PARALLEL'] = '1' if mode == 'sharded' else '0'
+    os.environ['NERF_SHARD_GROUPS'] = str(groups)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -82,19 +83,22 @@ def _worker(rank, world, port, q, mode, log2_T):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('mode,world,log2_T', [('dp', 2, 15), ('sharded', 2, 15), ('sharded', 3, 15), ('sharded', 2, 19),
-                                               ('dp', 2, 19)])
-def test_multi_rank_training_matches_single_process(mode, world, log2_T):
+@pytest.mark.parametrize('mode,world,log2_T,groups', [('dp', 2, 15, 1), ('sharded', 2, 15, 1), ('sharded', 3, 15, 1),
+                                                      ('sharded', 2, 19, 1), ('dp', 2, 19, 1), ('sharded', 2, 15, 3),
+                                                      ('sharded', 3, 19, 2), ('sharded', 2, 19, 4)])
+def test_multi_rank_training_matches_single_process(mode, world, log2_T, groups):
     """world 3 puts a rank in the middle (remote points on both sides of its own block) and splits 8 levels 3/3/2.
     log2_T 19 makes levels 5-7 hashed and large: the single process and the level owners then take the binned table
-    update (csrc/table_update.hip), the replicated 'dp' ranks the scatter -> all-reduce -> Adam pipeline."""
+    update (csrc/table_update.hip), the replicated 'dp' ranks the scatter -> all-reduce -> Adam pipeline.
+    groups > 1: both feature exchanges run per ray group (level_parallel.LevelSharding.plan; 63 or 42 rays per rank in
+    groups of 21 / 15-16 / 10-11 rays), the owners see the points of all ranks in group-major order."""
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode, log2_T)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode, log2_T, groups)) for r in range(world)]
     [p.start() for p in procs]
     got = q.get(timeout=150)
     [p.join(60) for p in procs]
