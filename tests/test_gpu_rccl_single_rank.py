@@ -61,6 +61,20 @@ assert abs(l0 - l1) < 1e-5, (l0, l1)
 for a, b in zip(sharded, plain):
     assert float(((a - b).abs() > 1e-5).float().mean()) < 0.02
     assert float((a - b).abs().max()) < 4e-2 + 1e-3      # a table entry whose tiny gradient flips sign moves by 2 lr
+# the same again with the exchanges cut into three ray groups (level_parallel.LevelSharding.plan): several RCCL
+# all-to-alls in flight at once, waited for in order, flags riding with the small gradients
+os.environ["NERF_SHARD_GROUPS"] = "3"
+l2, grouped = train(True, "base19")
+del os.environ["NERF_SHARD_GROUPS"]
+dist.barrier()
+assert abs(l2 - l1) < 1e-5, (l2, l1)
+for a, b in zip(grouped, sharded):
+    assert float(((a - b).abs() > 1e-5).float().mean()) < 0.02
+    assert float((a - b).abs().max()) < 4e-2 + 1e-3
+flag = torch.tensor([3.0], dtype=torch.float64, device="cuda")
+w_ = torch.nn.Parameter(torch.ones(4, device="cuda")); w_.grad = torch.full((4,), 2.0, device="cuda")
+parallel.all_reduce_grads([w_], flags=[flag])
+assert float(flag) == 3.0 and float(w_.grad.sum()) == 8.0
 # the helpers directly, incl. the empty own block of the list all-to-all
 x = torch.arange(12., device="cuda").view(4, 3)
 assert torch.equal(parallel.all_gather_rows(x), x)
