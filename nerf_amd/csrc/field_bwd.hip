@@ -21,10 +21,10 @@ constexpr int kSP = kBlockPts + 1;  // staging pitch (odd -> conflict-free row w
 // acc += SA[a_tile rows][:] * SB[b_tile rows][:]^T over the 128 staged points
 __device__ __forceinline__ f32x16 dw_tile(f32x16 acc, const float* SA, const float* SB, int a_tile, int b_tile, int n_out,
                                           int n_in, int l31, int h) {
+    // rows past n_out / n_in are clamped to row 0: they land in accumulator entries flush_tile never writes
     const int ar = a_tile * 32 + l31, br = b_tile * 32 + l31;
-    const bool al = ar < n_out, bl = br < n_in;
-    const float* pa = SA + (al ? ar : 0) * kSP + h;
-    const float* pb = SB + (bl ? br : 0) * kSP + h;
+    const float* pa = SA + (ar < n_out ? ar : 0) * kSP + h;
+    const float* pb = SB + (br < n_in ? br : 0) * kSP + h;
     constexpr int G = 4, NG = kBlockPts / 2 / G;
     float abuf[2][G], bbuf[2][G];
 #pragma unroll
@@ -35,8 +35,10 @@ __device__ __forceinline__ f32x16 dw_tile(f32x16 acc, const float* SA, const flo
 #pragma unroll
             for (int i = 0; i < G; ++i) { abuf[(gi + 1) & 1][i] = pa[2 * ((gi + 1) * G + i)]; bbuf[(gi + 1) & 1][i] = pb[2 * ((gi + 1) * G + i)]; }
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < G; ++i) acc = MFMA32(sel0(al, abuf[gi & 1][i]), sel0(bl, bbuf[gi & 1][i]), acc);
+        for (int i = 0; i < G; ++i) acc = MFMA32(abuf[gi & 1][i], bbuf[gi & 1][i], acc);
+        __builtin_amdgcn_sched_barrier(0);
     }
     return acc;
 }
@@ -95,7 +97,7 @@ __device__ __forceinline__ f32x16 relu_mask(const f32x16& d, const f32x16& act) 
     return r;
 }
 
-template <int F, int XF>
+template <int F, int XF, bool REF>
 __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, const float* __restrict__ sigma_w,
                                                            const float* __restrict__ color_w,
                                                            const float* __restrict__ latent, NerfPointSrc src,
@@ -154,7 +156,8 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
             const float* w1r1 = w1r0 + 32 * kPS1;
             f32x16 acc[2] = {zero16(), zero16()};
             // steps past LH*F (generic XF = 32 build) multiply by xf = 0
-            mfma_chain<XF, 2>(acc, [&](int t, int n) { return (n ? w1r1 : w1r0)[t < LHF ? t : 0]; }, [&](int t) { return xf[t % XF]; });
+            // (steps past LH*F of the generic XF = 32 build read the other half's weights or the zero pad: times xf = 0)
+            mfma_chain<XF, 2>(acc, [&](int t, int n) { return (n ? w1r1 : w1r0)[t]; }, [&](int t) { return xf[t % XF]; });
             a0 = acc[0];
             a1 = acc[1];
         }
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
         {
             float sh[16];
             sh16(q.dx, q.dy, q.dz, sh);
-            color_layer1(lds, s, l31, h, o2, sh, lat, c0, c1);
+            color_layer1<REF>(lds, s, l31, h, o2, sh, lat, c0, c1);
         }
         c0 = relu16(c0);
         c1 = relu16(c1);
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
             mfma_chain<32, 2>(acc,
                               [&](int st, int n) {
                                   const int kk = (krow64(st) + 4 * h) * kPC1;
-                                  return n ? sel0(liveL, wL[kk]) : sel0(liveG, wG[kk]);
+                                  return n ? wL[kk] : wG[kk];      // dead rows: never read back
                               },
                               [&](int st) { return st < 16 ? g0[st & 15] : g1[st & 15]; });
             dG = acc[0];
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
             mfma_chain<32, 2>(acc,
                               [&](int st, int n) {
                                   const int kk = (krow64(st) + 4 * h) * kPS1;
-                                  return n ? sel0(live1, w1[kk]) : sel0(live0, w0[kk]);
+                                  return n ? w1[kk] : w0[kk];      // dead rows: never stored
                               },
                               [&](int st) { return st < 16 ? g0[st & 15] : g1[st & 15]; });
             x0 = acc[0];
@@ -403,13 +406,20 @@ extern "C" int nerf_field_bwd(const NerfGridCfg* grid, const NerfNetCfg* net, co
     const int64_t n_btiles = ceil_div64(src->n_points, kBlockPts);
     const unsigned nb = (unsigned)(n_btiles < kNumCU ? n_btiles : kNumCU);
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH2(FF, XX)                                                                                                \
+#define LAUNCH3(FF, XX, RR)                                                                                            \
     do {                                                                                                               \
-        auto kern = field_bwd_kernel<FF, XX>;                                                                            \
+        auto kern = field_bwd_kernel<FF, XX, RR>;                                                                        \
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);  \
         if (e != hipSuccess) { nerf_set_error("field_bwd: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }  \
         kern<<<nb, 256, lds_bytes, st>>>(g, s, sigma_params, color_params, latent_emb, *src, x_hashtable, dsigma, drgb, \
                                          dfeat, dsigma_params, dcolor_params, dlatent, sb_rows);                       \
+    } while (0)
+    // the reference's colour-net input (SH degree 4 + latent 48) gets its layer-1 input map at compile time
+    const bool ref_shape = s.sh_half == 8 && s.lat_half == 24;
+#define LAUNCH2(FF, XX)                                  \
+    do {                                                 \
+        if (ref_shape) LAUNCH3(FF, XX, true);            \
+        else LAUNCH3(FF, XX, false);                     \
     } while (0)
 #define LAUNCH(FF)                                       \
     do {                                                 \
@@ -424,6 +434,7 @@ extern "C" int nerf_field_bwd(const NerfGridCfg* grid, const NerfNetCfg* net, co
     }
 #undef LAUNCH
 #undef LAUNCH2
+#undef LAUNCH3
     rc = nerf_launch_status("nerf_field_bwd");
     if (rc || !dtable) return rc;
     return nerf_hashgrid_scatter(grid, src, dfeat, dtable, 0, grid->n_levels, stream);

@@ -44,7 +44,7 @@ constexpr int kWC1 = kWS2 + kGeoRows * kPS2;
 constexpr int kWC2 = kWC1 + kHid * kPC1;
 constexpr int kWC3 = kWC2 + kHid * kPC2;
 constexpr int kNetLdsSigma = kWC1;              // floats: sigma net only
-constexpr int kNetLdsFull = kWC3 + 3 * kPC3;    // floats: both nets
+constexpr int kNetLdsFull = kWC3 + 8 * kPC3;    // floats: both nets (colour layer 3: rows 3..7 stay zero, see layer_T_Nx64)
 
 struct NetLds {
     int in_s;    // L*F
@@ -304,11 +304,14 @@ __device__ __forceinline__ void mfma_chain(f32x16 (&acc)[NT], AFn a_at, BFn b_at
 #pragma unroll
             for (int n = 0; n < NT; ++n)
                 if ((g + 1) * G + s < STEPS) buf[(g + 1) & 1][s * NT + n] = a_at((g + 1) * G + s, n);
+        // nothing crosses: the scheduler otherwise sinks every read to right before its MFMA again (shortest live range)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < G; ++s)
 #pragma unroll
             for (int n = 0; n < NT; ++n)
                 if (g * G + s < STEPS) acc[n] = MFMA32(buf[g & 1][s * NT + n], b_at(g * G + s), acc[n]);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -332,27 +335,25 @@ __device__ __forceinline__ void layer_64x64(const float* w, int l31, int h, cons
 template <int pitch>
 __device__ __forceinline__ f32x16 layer_64xN(const float* w, int n_out, int l31, int h, const f32x16& i0,
                                              const f32x16& i1) {
-    const bool live = l31 < n_out;
-    const float* r0 = w + (live ? l31 : 0) * pitch + 4 * h;
+    // lanes past n_out read row 0 again: their output rows are copies of row 0 that no caller consumes (a select on
+    // the loaded value would pin every ds_read to an s_waitcnt right behind it)
+    const float* r0 = w + (l31 < n_out ? l31 : 0) * pitch + 4 * h;
     f32x16 acc[1] = {zero16()};
-    mfma_chain<32, 1>(acc, [&](int s, int) { return sel0(live, r0[krow64(s)]); },
+    mfma_chain<32, 1>(acc, [&](int s, int) { return r0[krow64(s)]; },
                       [&](int s) { return s < 16 ? i0[s & 15] : i1[s & 15]; });
     return acc[0];
 }
 
 // d_in(64) = W^T * d_out where d_out has n_out live rows held in registers t < NSTEPS
-// (n_out = 16 -> NSTEPS 8, n_out = 3 -> NSTEPS 3).
+// (n_out = 16 -> NSTEPS 8, n_out = 3 -> NSTEPS 3).  The caller passes d with ZEROS in its rows >= n_out, and the LDS
+// image holds zero rows up to krow(NSTEPS-1) + 4 (kNetLdsFull), so neither operand needs a select.
 template <int NSTEPS, int pitch>
 __device__ __forceinline__ void layer_T_Nx64(const float* w, int n_out, int l31, int h, const f32x16& d,
                                              f32x16& o0, f32x16& o1) {
+    (void)n_out;
+    const float* r = w + 4 * h * pitch + l31;
     f32x16 acc[2] = {zero16(), zero16()};
-    mfma_chain<NSTEPS, 2>(acc,
-                          [&](int s, int n) {
-                              const int k = krow(s) + 4 * h;
-                              const bool live = k < n_out;
-                              return sel0(live, w[(live ? k : 0) * pitch + l31 + 32 * n]);
-                          },
-                          [&](int s) { return sel0(krow(s) + 4 * h < n_out, d[s & 15]); });
+    mfma_chain<NSTEPS, 2>(acc, [&](int s, int n) { return r[krow(s) * pitch + 32 * n]; }, [&](int s) { return d[s & 15]; });
     o0 = acc[0];
     o1 = acc[1];
 }
@@ -371,8 +372,35 @@ __device__ __forceinline__ void layer_T_64x64(const float* w, int l31, int h, co
 
 // Colour layer 1 on [geo(15) | SH | latent]: 8 + 8 + 24 k-steps, the two lane halves splitting every
 // group (inactive steps of smaller configurations multiply by zero).  o2 = sigma-net output rows.
+// REF: the reference's shape (SH degree 4, latent 48) with its step -> input map as compile-time offsets.
+template <bool REF = false>
 __device__ __forceinline__ void color_layer1(const float* lds, const NetLds& s, int l31, int h, const f32x16& o2,
                                              const float (&sh)[16], const float (&lat)[24], f32x16& c0, f32x16& c1) {
+    if (REF) {
+        // in(st, h) = krow(st) - 1 + 4h | 15 + (st-8) + 8h | 31 + (st-16) + 24h: one base pointer per segment carries the
+        // lane half, the rest folds into the immediate offset of the ds_read.  (st = 0, h = 0 is the sigma row: it reads
+        // the pad float in front of the row and multiplies it by the zero below.)
+        const float* wg = lds + kWC1 + l31 * kPC1 + 4 * h;
+        const float* ws = lds + kWC1 + l31 * kPC1 + 8 * h;
+        const float* wl = lds + kWC1 + l31 * kPC1 + 24 * h;
+        f32x16 acc[2] = {zero16(), zero16()};
+        mfma_chain<40, 2>(
+            acc,
+            [&](int st, int n) {
+                const int o = n * 32 * kPC1;
+                if (st < 8) return wg[o + krow(st) - 1];
+                if (st < 16) return ws[o + 15 + (st - 8)];
+                return wl[o + 31 + (st - 16)];
+            },
+            [&](int st) {
+                if (st < 8) return (krow(st) + 4 * h == 0) ? 0.f : o2[st & 7];
+                if (st < 16) return h ? sh[st & 15] : sh[(st - 8) & 15];
+                return lat[(st - 16) % 24];
+            });
+        c0 = acc[0];
+        c1 = acc[1];
+        return;
+    }
     const float* wc0 = lds + kWC1 + l31 * kPC1;
     const float* wc1 = wc0 + 32 * kPC1;
     const int sh_base = 15 + h * s.sh_half, lat_base = 15 + s.sh_dim + h * s.lat_half;

@@ -8,11 +8,16 @@
 
 namespace {
 
+#ifndef NERF_FWD_THREADS
+#define NERF_FWD_THREADS 512   // 768 (three waves per SIMD, 167 VGPRs) measured slower: 0.669 vs 0.611 ms, more gathers in flight only thrash the L2
+#endif
+constexpr int kFwdMaxThreads = NERF_FWD_THREADS;
+
 // One wavefront = 32 points x 2 lane halves; lane half h gathers levels [h*LH, h*LH + LH).
 // FEATS: the hash-grid features come ready-made from xh_in (level-sharded table: the level owners encoded
 // them and an all-to-all brought them here) instead of being gathered from `table`.
 template <int F, bool COLOR, bool FEATS>
-__global__ __launch_bounds__(512) void field_fwd_kernel(GridDev g, NetLds s, const float* __restrict__ table,
+__global__ __launch_bounds__(kFwdMaxThreads) void field_fwd_kernel(GridDev g, NetLds s, const float* __restrict__ table,
                                                         const float* __restrict__ sigma_w,
                                                         const float* __restrict__ color_w,
                                                         const float* __restrict__ latent, NerfPointSrc src,
@@ -464,8 +469,9 @@ static int launch_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const floa
     const int stage_wave_floats = kTilePts * grid->n_levels * grid->n_features;
     if (!FEATS && xh && src->n_points >= (int64_t)kNumCU * 512 / 2) {
         const int off = (s.total + 3) & ~3;
-        const int need = (off + 8 * stage_wave_floats) * (int)sizeof(float);
-        if (need <= 112 * 1024) { threads = 512; stage_off = off; lds_bytes = need; }
+        const int big = kFwdMaxThreads / 64;
+        const int need = (off + big * stage_wave_floats) * (int)sizeof(float);
+        if (need <= 112 * 1024) { threads = kFwdMaxThreads; stage_off = off; lds_bytes = need; }
     }
     const int waves = threads / 64;
     hipStream_t st = (hipStream_t)stream;
@@ -476,7 +482,7 @@ static int launch_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const floa
         if (e != hipSuccess) { nerf_set_error("field_fwd: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }  \
         static int per_cu = 0, per_cu_lds = -1;     /* per instantiation; the net shape rarely changes */              \
         if (per_cu_lds != lds_bytes) { per_cu = resident_blocks_per_cu(kern, threads, lds_bytes); per_cu_lds = lds_bytes; } \
-        const unsigned nb = fwd_grid(src->n_points, threads == 512 ? (per_cu > 1 ? 1 : per_cu) : per_cu, waves, COLOR);   \
+        const unsigned nb = fwd_grid(src->n_points, threads > 256 ? (per_cu > 1 ? 1 : per_cu) : per_cu, waves, COLOR);   \
         kern<<<nb, threads, lds_bytes, st>>>(g, s, table, sw, cw, latent, *src, sigma, rgb, xh, xyz, xh_in, stage_off); \
     } while (0)
     switch (grid->n_features) {
