@@ -280,6 +280,14 @@ int64_t nerf_table_bin_workspace_bytes(const NerfGridCfg* grid, const NerfLevelS
 int nerf_table_bin_levels(const NerfGridCfg* grid, const NerfPointSrc* src, const NerfLevelSet* levels, const float* dfeat,
                           int64_t dfeat_stride, const int32_t* dfeat_cols, void* workspace, int64_t workspace_bytes,
                           void* stream);
+/* The two halves of nerf_table_bin_levels: the count + scan passes need only the points (known once the fine depths are
+ * sampled), the fill pass needs the gradient rows.  A caller may issue the first half early, e.g. on a side stream under
+ * the field forward; the fill must see the SAME src, levels and workspace, untouched in between. */
+int nerf_table_bin_count(const NerfGridCfg* grid, const NerfPointSrc* src, const NerfLevelSet* levels, void* workspace,
+                         int64_t workspace_bytes, void* stream);
+int nerf_table_bin_fill(const NerfGridCfg* grid, const NerfPointSrc* src, const NerfLevelSet* levels, const float* dfeat,
+                        int64_t dfeat_stride, const int32_t* dfeat_cols, void* workspace, int64_t workspace_bytes,
+                        void* stream);
 /* table / exp_avg / exp_avg_sq: the WHOLE table's tensors (level offsets come from grid); only the listed levels change.
  * n_points and levels must be those of the nerf_table_bin_levels call that filled the workspace. */
 int nerf_table_update_binned(const NerfGridCfg* grid, const NerfLevelSet* levels, int64_t n_points, const void* workspace,

@@ -514,21 +514,27 @@ extern "C" int64_t nerf_table_bin_workspace_bytes(const NerfGridCfg* grid, const
     return rc ? (int64_t)(rc < 0 ? rc : -rc) : lay.total;
 }
 
-extern "C" int nerf_table_bin_levels(const NerfGridCfg* grid, const NerfPointSrc* src, const NerfLevelSet* levels,
-                                     const float* dfeat, int64_t dfeat_stride, const int32_t* dfeat_cols, void* workspace,
-                                     int64_t workspace_bytes, void* stream) {
-    NERF_REQUIRE(grid && dfeat && workspace, "null pointer");
-    int rc = nerf_check_src("nerf_table_bin_levels", src, false);
+namespace {
+
+// count + scan (which need only the points) and / or the fill (which needs the gradient rows) of nerf_table_bin_levels
+int bin_passes(const char* fn, const NerfGridCfg* grid, const NerfPointSrc* src, const NerfLevelSet* levels, const float* dfeat,
+               int64_t dfeat_stride, const int32_t* dfeat_cols, void* workspace, int64_t workspace_bytes, void* stream,
+               bool do_count, bool do_fill) {
+    if (!grid || !workspace || (do_fill && !dfeat)) { nerf_set_error("%s: null pointer", fn); return NERF_EINVAL; }
+    int rc = nerf_check_src(fn, src, false);
     if (rc) return rc;
     BinPlan plan;
     BinLayout lay;
-    rc = make_plan("nerf_table_bin_levels", grid, levels, src->n_points, dfeat_cols, &plan, &lay);
+    rc = make_plan(fn, grid, levels, src->n_points, dfeat_cols, &plan, &lay);
     if (rc) return rc;
-    NERF_REQUIRE(workspace_bytes >= lay.total && (((uintptr_t)workspace) & 15) == 0, "workspace too small or not 16-byte aligned");
+    if (workspace_bytes < lay.total || (((uintptr_t)workspace) & 15) != 0) {
+        nerf_set_error("%s: workspace too small or not 16-byte aligned", fn); return NERF_EINVAL;
+    }
     if (src->n_points == 0) return 0;       // nothing to sort; nerf_table_update_binned(n_points = 0) reads no bins
     const int F = grid->n_features;
-    for (int i = 0; i < plan.count; ++i)
-        NERF_REQUIRE(dfeat_stride >= plan.col[i] + F, "dfeat_stride smaller than the last gradient column");
+    if (do_fill)
+        for (int i = 0; i < plan.count; ++i)
+            if (dfeat_stride < plan.col[i] + F) { nerf_set_error("%s: dfeat_stride smaller than the last gradient column", fn); return NERF_EINVAL; }
     const GridDev g = make_grid_dev(grid);
     char* ws = (char*)workspace;
     uint32_t* hist = (uint32_t*)(ws + lay.hist);
@@ -546,15 +552,17 @@ extern "C" int nerf_table_bin_levels(const NerfGridCfg* grid, const NerfPointSrc
     const bool sorted = sorted_lds <= 150 * 1024 && !getenv("NERF_BIN_FILL_PLAIN");
 #define BIN_PASSES(FF)                                                                                                 \
     do {                                                                                                               \
-        bin_count_kernel<FF><<<nb, kBinThreads, 0, st>>>(g, *src, plan, M, lay.nwg, hist);                             \
-        bin_scan_kernel<<<(unsigned)plan.count, kBinThreads, 0, st>>>(plan, lay.nwg, hist, bin_start);                 \
-        if (sorted) {                                                                                                  \
+        if (do_count) {                                                                                                \
+            bin_count_kernel<FF><<<nb, kBinThreads, 0, st>>>(g, *src, plan, M, lay.nwg, hist);                         \
+            bin_scan_kernel<<<(unsigned)plan.count, kBinThreads, 0, st>>>(plan, lay.nwg, hist, bin_start);             \
+        }                                                                                                              \
+        if (do_fill && sorted) {                                                                                       \
             auto kern = bin_fill_sorted_kernel<FF>;                                                                    \
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, sorted_lds); \
-            if (e != hipSuccess) { nerf_set_error("nerf_table_bin_levels: LDS attribute: %s", hipGetErrorString(e)); return (int)e; } \
+            if (e != hipSuccess) { nerf_set_error("%s: LDS attribute: %s", fn, hipGetErrorString(e)); return (int)e; }  \
             kern<<<nb, kBinThreads, sorted_lds, st>>>(g, *src, plan, M, lay.nwg, nb_max, hist, dfeat, dfeat_stride, item_idx, \
                                                       item_val);                                                       \
-        } else {                                                                                                       \
+        } else if (do_fill) {                                                                                          \
             bin_fill_kernel<FF><<<nb, kBinThreads, 0, st>>>(g, *src, plan, M, lay.nwg, hist, dfeat, dfeat_stride, item_idx, \
                                                             item_val);                                                 \
         }                                                                                                              \
@@ -565,7 +573,29 @@ extern "C" int nerf_table_bin_levels(const NerfGridCfg* grid, const NerfPointSrc
         default: BIN_PASSES(4); break;
     }
 #undef BIN_PASSES
-    return nerf_launch_status("nerf_table_bin_levels");
+    return nerf_launch_status(fn);
+}
+
+}  // namespace
+
+extern "C" int nerf_table_bin_levels(const NerfGridCfg* grid, const NerfPointSrc* src, const NerfLevelSet* levels,
+                                     const float* dfeat, int64_t dfeat_stride, const int32_t* dfeat_cols, void* workspace,
+                                     int64_t workspace_bytes, void* stream) {
+    return bin_passes("nerf_table_bin_levels", grid, src, levels, dfeat, dfeat_stride, dfeat_cols, workspace, workspace_bytes,
+                      stream, true, true);
+}
+
+extern "C" int nerf_table_bin_count(const NerfGridCfg* grid, const NerfPointSrc* src, const NerfLevelSet* levels,
+                                    void* workspace, int64_t workspace_bytes, void* stream) {
+    return bin_passes("nerf_table_bin_count", grid, src, levels, nullptr, 0, nullptr, workspace, workspace_bytes, stream, true,
+                      false);
+}
+
+extern "C" int nerf_table_bin_fill(const NerfGridCfg* grid, const NerfPointSrc* src, const NerfLevelSet* levels,
+                                   const float* dfeat, int64_t dfeat_stride, const int32_t* dfeat_cols, void* workspace,
+                                   int64_t workspace_bytes, void* stream) {
+    return bin_passes("nerf_table_bin_fill", grid, src, levels, dfeat, dfeat_stride, dfeat_cols, workspace, workspace_bytes,
+                      stream, false, true);
 }
 
 extern "C" int nerf_table_update_binned_guarded(const NerfGridCfg* grid, const NerfLevelSet* levels, int64_t n_points,

@@ -7,6 +7,7 @@ replaced by small modules holding one flat fp32 ``params`` tensor each; the arit
 libnerf_hip.so (fused hash-grid gather + MFMA MLP chains), in fp32 throughout.
 """
 import ctypes as C
+import os
 import math
 
 import torch
@@ -159,6 +160,9 @@ def _slice_src_kwargs(kw, a, b, unit):
     return out
 
 
+EARLY_BIN_COUNT = os.environ.get('NERF_EARLY_BIN_COUNT', '1') != '0'
+
+
 class _FieldFn(torch.autograd.Function):
     """sigma, rgb = field(points); backward = nerf_field_bwd (gradients for table, MLPs, latent)."""
 
@@ -172,6 +176,12 @@ class _FieldFn(torch.autograd.Function):
         xh = torch.empty(M, net.encoder.n_output_dims, device=dev, dtype=torch.float32)
         xyz = torch.empty(M, 3, device=dev, dtype=torch.float32) if want_xyz else None
         lat = latent if latent is not None else None
+        pipe = net.table_pipeline
+        ctx.count_tag = None
+        if pipe is not None and net.direct_grads and pipe.binned_levels and ctx.needs_input_grad[0] and EARLY_BIN_COUNT:
+            # the count + scan passes of the binned table update, issued BEFORE the field kernel so that they run beside it
+            ctx.count_tag = net.forward_count = getattr(net, 'forward_count', 0) + 1
+            pipe.count_early(net.encoder.cfg, src, ctx.count_tag, dev)
         check(lib().nerf_field_fwd(C.byref(net.encoder.cfg), C.byref(net.net_cfg), ptr(table), ptr(sigma_w), ptr(color_w),
                                    ptr(lat), net.N, C.byref(src), ptr(sigma), ptr(rgb), ptr(xh), ptr(xyz), stream()),
               'nerf_field_fwd')
@@ -227,7 +237,8 @@ class _FieldFn(torch.autograd.Function):
                 with torch.cuda.stream(pipe.scatter_stream):
                     pipe.scatter_stream.wait_event(done)
                     net.scatter_levels_pipelined(src, dfeat, dtable, final=True)
-            pipe.bin(net.encoder.cfg, src, dfeat, dfeat.shape[1], net.encoder.level_cols, dtable, keepalive=ctx.src_kwargs)
+            pipe.bin(net.encoder.cfg, src, dfeat, dfeat.shape[1], net.encoder.level_cols, dtable, keepalive=ctx.src_kwargs,
+                     tag=ctx.count_tag)
         elif pipe is None or not direct or cut * unit < 65536 or (rows - cut) * unit < 65536:
             check(lib().nerf_field_bwd(C.byref(net.encoder.cfg), C.byref(net.net_cfg), ptr(table), ptr(sigma_w), ptr(color_w),
                                        ptr(latent), net.N, C.byref(src), ptr(xh), ptr(dsigma), ptr(drgb),

@@ -69,6 +69,9 @@ class TablePipeline(object):
         self.works = {}
         self.side = None
         self.scatter_stream = None      # carries the scatter of the first backward chunk (see _FieldFn.backward)
+        self.count_stream = None        # carries the early count + scan passes of the binned update (count_early)
+        self.count_tag = None
+        self.count_done = None
         self.early_fraction = float(os.environ.get('NERF_BWD_SPLIT', '0.35'))
         self.pending = False
         self.dtable = None
@@ -82,20 +85,52 @@ class TablePipeline(object):
         self.keep = []
 
     # ---- binned levels ---------------------------------------------------------------------------------
-    def bin(self, cfg, src, dfeat, stride, cols, dtable, keepalive=None):
-        """Sort the corner updates of this backward pass into table partitions (no optimizer hyper-parameters needed
-        yet; FusedAdam.step applies them with nerf_table_update_binned).  `cols`: {level: first gradient column in a
-        row of dfeat}; `keepalive`: whatever owns the memory `src` points into (it must outlive this pass when a
-        later backward has to replay it).  One backward per step is the fast path: a second backward before step() -- gradient
-        accumulation -- falls back to the atomic scatter into p.grad."""
-        if not self.binned_levels:
-            return
+    def _binned_setup(self, cfg, n_points, device):
         if self.binned_set is None:
             ls = NerfLevelSet()
             ls.count = len(self.binned_levels)
             for i, l in enumerate(self.binned_levels):
                 ls.level[i] = l
             self.binned_set = ls
+        nbytes = lib().nerf_table_bin_workspace_bytes(C.byref(cfg), C.byref(self.binned_set), n_points)
+        if nbytes < 0:
+            check(int(nbytes), 'nerf_table_bin_workspace_bytes')
+        if self.binned_ws is None or self.binned_ws.numel() < nbytes:
+            if self.count_done is not None:
+                self.count_done.synchronize()       # an early count pass may still be writing the old workspace
+            self.binned_ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+
+    def count_early(self, cfg, src, tag, device):
+        """The count + scan passes of bin() need only the points: issued from the FORWARD pass on a side stream they run
+        under the field forward (which is bound by random gathers, while the count pass is index arithmetic + an LDS
+        histogram) instead of between the backward kernel and the fill.  `tag` identifies the forward whose backward may
+        use the counts; any other backward (a second forward in between, gradient accumulation) counts again."""
+        self.count_tag = None
+        if not self.binned_levels or self.binned_pending is not None or self.binned_fallback or src.n_points == 0:
+            return
+        self._binned_setup(cfg, src.n_points, device)
+        if self.count_stream is None:
+            self.count_stream = torch.cuda.Stream()
+        ready = torch.cuda.Event()
+        ready.record()      # the points exist, and every earlier reader of the workspace (the last update pass) was issued
+        with torch.cuda.stream(self.count_stream):
+            self.count_stream.wait_event(ready)
+            check(lib().nerf_table_bin_count(C.byref(cfg), C.byref(src), C.byref(self.binned_set), ptr(self.binned_ws),
+                                             self.binned_ws.numel(), stream()), 'nerf_table_bin_count')
+            self.count_done = torch.cuda.Event()
+            self.count_done.record()
+        self.count_tag = (tag, src.n_points, self.binned_ws.data_ptr())
+
+    def bin(self, cfg, src, dfeat, stride, cols, dtable, keepalive=None, tag=None):
+        """Sort the corner updates of this backward pass into table partitions (no optimizer hyper-parameters needed
+        yet; FusedAdam.step applies them with nerf_table_update_binned).  `cols`: {level: first gradient column in a
+        row of dfeat}; `keepalive`: whatever owns the memory `src` points into (it must outlive this pass when a
+        later backward has to replay it).  One backward per step is the fast path: a second backward before step() -- gradient
+        accumulation -- falls back to the atomic scatter into p.grad.  `tag`: see count_early."""
+        if not self.binned_levels:
+            return
+        counted = getattr(self, 'count_tag', None)
+        self.count_tag = None
         if self.binned_pending is not None or self.binned_fallback:
             if self.binned_pending is not None:         # move the earlier pass's updates into the gradient
                 src0, dfeat0, stride0, cols0, _alive = self.binned_keep
@@ -104,15 +139,17 @@ class TablePipeline(object):
             self.binned_fallback = True
             self._scatter_classic(cfg, src, dfeat, stride, cols, dtable)
             return
-        nbytes = lib().nerf_table_bin_workspace_bytes(C.byref(cfg), C.byref(self.binned_set), src.n_points)
-        if nbytes < 0:
-            check(int(nbytes), 'nerf_table_bin_workspace_bytes')
-        if self.binned_ws is None or self.binned_ws.numel() < nbytes:
-            self.binned_ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dfeat.device)
+        self._binned_setup(cfg, src.n_points, dfeat.device)
         col_arr = (C.c_int32 * len(self.binned_levels))(*[int(cols[l]) for l in self.binned_levels])
-        check(lib().nerf_table_bin_levels(C.byref(cfg), C.byref(src), C.byref(self.binned_set), ptr(dfeat), stride,
-                                          col_arr, ptr(self.binned_ws), self.binned_ws.numel(), stream()),
-              'nerf_table_bin_levels')
+        if self.count_done is not None:      # whatever count pass is still in flight writes this workspace
+            torch.cuda.current_stream().wait_event(self.count_done)
+        if tag is not None and counted == (tag, src.n_points, self.binned_ws.data_ptr()):
+            check(lib().nerf_table_bin_fill(C.byref(cfg), C.byref(src), C.byref(self.binned_set), ptr(dfeat), stride, col_arr,
+                                            ptr(self.binned_ws), self.binned_ws.numel(), stream()), 'nerf_table_bin_fill')
+        else:
+            check(lib().nerf_table_bin_levels(C.byref(cfg), C.byref(src), C.byref(self.binned_set), ptr(dfeat), stride,
+                                              col_arr, ptr(self.binned_ws), self.binned_ws.numel(), stream()),
+                  'nerf_table_bin_levels')
         self.binned_pending = (src.n_points, self.binned_ws.numel())
         self.binned_keep = (src, dfeat, stride, cols, keepalive)
 

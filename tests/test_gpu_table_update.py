@@ -174,6 +174,54 @@ def test_binned_mode_handles_gradient_accumulation_and_discarded_backward(n_back
     assert float(((p1 - p0).abs() > 1e-5).float().mean()) < 1e-3
 
 
+def _early_run(early, monkeypatch, interleave=False):
+    from nerf_amd import helpers, nets
+    from nerf_amd.optim import FusedAdam
+    from nerf_amd.renderer import NerfRenderer
+    from test_gpu_parity import NET_CFGS, _batch, _make_pair
+    monkeypatch.setattr(nets, 'EARLY_BIN_COUNT', early)
+    net, _ = _make_pair(NET_CFGS['base19'])
+    R = NerfRenderer(net, 2, 2.5, [1.6, 4.8], [64], 128, 0.2)
+    opt = FusedAdam([{'params': list(net.encoder.parameters()) + [net.latent_emb], 'lr': 2e-2},
+                     {'params': list(net.sigma_net.parameters()) + list(net.color_net.parameters()), 'lr': 1e-3}],
+                    betas=(0.9, 0.99), eps=1e-8).attach(net)
+    used = 0
+    for step in range(2):
+        opt.zero_grad()
+        n, h, w, K, E, bg, noise, gt = [t.cuda() for t in _batch(30 + step, 160)]
+        img, wts, zs, _ = R.render(n, h, w, K, E, bg, noise=noise)
+        if interleave and step == 1:
+            # a second forward (other rays, never back-propagated) between this forward and its backward: its early count
+            # pass overwrites the counters, so the backward must count again
+            n2, h2, w2, K2, E2, bg2, noise2, _ = [t.cuda() for t in _batch(77, 96)]
+            R.render(n2, h2, w2, K2, E2, bg2, noise=noise2)
+        loss, _ = helpers.fused_train_loss(img, gt, wts, zs, 1e-3, 1e-1)
+        loss.backward()
+        used += int(net.table_pipeline.binned_pending is not None)
+        opt.step()
+    torch.cuda.synchronize()
+    assert used == 2        # the binned path, not the accumulation fallback
+    st = opt.state[net.encoder.params]
+    return net.encoder.params.detach().clone(), st['exp_avg'].clone(), st['exp_avg_sq'].clone()
+
+
+@pytest.mark.parametrize('interleave', [False, True])
+def test_early_count_pass_changes_nothing(interleave, monkeypatch):
+    """The count + scan passes of the binned update issued from the forward pass on a side stream (TablePipeline.count_early)
+    against the same passes issued in the backward: the same counters, so the same bins (the order of the items inside a
+    bin depends on the LDS atomics of the fill pass in either case, hence the comparison up to summation order, with the
+    bars of the accumulation test above: a lost, doubled or misplaced run of items would be off by tens of percent).
+    With a foreign forward between a forward and its backward the early counts are stale and must not be used.
+    (Run-to-run spread of either mode on one box, tools/early_count_probe.py: moments 2e-4 ... 1e-3 in relative L2.)"""
+    p1, m1, v1 = _early_run(True, monkeypatch, interleave)
+    p0, m0, v0 = _early_run(False, monkeypatch, interleave)
+    assert float(m0.abs().max()) > 0
+    for a, b in ((m1, m0), (v1, v0)):
+        assert float((a - b).norm() / b.norm()) < 1e-2
+        assert float(((a - b).abs() > 1e-4 * float(b.abs().max())).float().mean()) < 2e-3
+    assert float(((p1 - p0).abs() > 1e-5).float().mean()) < 1e-2
+
+
 def test_update_on_a_foreign_workspace_stays_in_bounds():
     """nerf_table_update_binned on a workspace that nerf_table_bin_levels never filled (random bytes): the result is
     garbage, but every read and write stays inside the workspace and the listed levels (no GPU fault, levels outside
