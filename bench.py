@@ -337,7 +337,7 @@ def main():
             lv = int(cls[1:].split(' ')[0])             # levels per launch
             per_level = n_pts_scatter * (2 * 8 * 2 * 4 + 2 * 4)     # RMW of 8 corners x F floats + F floats of dfeat
             bytes_step = per_level * lv * (launches / args.profile_steps) / n_chunks
-        elif base in ('nerf_table_update_binned', 'nerf_table_bin_levels') and pipe is not None and pipe.binned_levels:
+        elif base in ('nerf_table_update_binned', 'nerf_table_bin_levels', 'nerf_table_bin_fill') and pipe is not None and pipe.binned_levels:
             # binned table update (csrc/table_update.hip): an item = one corner update = 2 B index + 4F B values;
             # the update pass moves 24 B per parameter (p, m, v read and written) and reads every item once; the bin
             # passes read d(features) once per level and write every item once
@@ -411,7 +411,8 @@ def main():
         # binned table update: the LDS-privatised scatter of the small dense levels runs on its own stream BESIDE the
         # bin and update passes (its wall time is stretched by sharing the CUs and is not on the critical path), so
         # the dominant kernel is picked among the launches of the main stream
-        with_bytes = [k for k in with_bytes if not k['name'].startswith('nerf_hashgrid_scatter')]
+        # (so do the count + scan passes, issued from the forward pass: nerf_table_bin_count)
+        with_bytes = [k for k in with_bytes if not k['name'].startswith(('nerf_hashgrid_scatter', 'nerf_table_bin_count'))]
     roofline = roofline_of(with_bytes[0]) if with_bytes else None
     if roofline and roofline['kernel'] == 'nerf_table_update_binned':
         roofline['note'] = ('scatter + Adam of the hashed and large dense levels in one pass: every bin of corner updates is '
@@ -419,8 +420,10 @@ def main():
     if roofline and roofline['kernel'].startswith('nerf_hashgrid_scatter'):
         roofline['note'] = ('random 8-byte atomic adds: bounded by the memory-side atomic rate (one 64-B request per table '
                             'entry), not by bytes; the launches overlap the Adam pass of the previous level')
-    # the second-largest class, for reference (the Adam pass streams at the HBM roofline)
-    roofline_2 = roofline_of(with_bytes[1]) if len(with_bytes) > 1 else None
+    # second: the kernel of the OTHER bound, the matrix-core-bound MLP backward with its counter-based MFMA utilisation
+    # (else the second-largest class)
+    bwd = [k for k in kernels if k['name'].split('[')[0] == 'nerf_field_bwd']
+    roofline_2 = roofline_of(bwd[0]) if bwd else (roofline_of(with_bytes[1]) if len(with_bytes) > 1 else None)
 
     # ---- 800x800 inference (BASELINE configs[1]) ----
     render = None
