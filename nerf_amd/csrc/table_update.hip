@@ -202,6 +202,9 @@ __global__ __launch_bounds__(kBinThreads) void bin_fill_kernel(GridDev g, NerfPo
 // (the plain kernel writes 2.0 GB for 0.63 GB of items -- partially filled lines are evicted and rewritten).
 // Dynamic LDS: cur[nb] | cnt[nb] | start[nb] | wave sums | staged keys (u32: bin, offset), values.
 constexpr int kSortPts = kBinThreads;       // one point per thread and round
+#ifndef NERF_FILL_ABL
+#define NERF_FILL_ABL 0      // timing ablations of the fill pass (tools/fill_ablation.sh): never in a shipped build
+#endif
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
 #pragma unroll
@@ -278,12 +281,13 @@ __global__ __launch_bounds__(kBinThreads) void bin_fill_sorted_kernel(GridDev g,
                 const uint32_t fl = c.idx[k] * (uint32_t)F + plan.shift[slot];
                 bin[k] = fl / kPartFloats;
                 loc[k] = fl % kPartFloats;
-                rank[k] = atomicAdd(&cnt[bin[k]], 1u);
+                rank[k] = NERF_FILL_ABL >= 4 ? (uint32_t)k : atomicAdd(&cnt[bin[k]], 1u);
 #pragma unroll
                 for (int f = 0; f < F; ++f) val[k][f] = c.w[k] * d[f];
             }
         }
         lds_sync();
+        if (NERF_FILL_ABL >= 3) continue;
         // exclusive scan of cnt[0..nb) -> start
         uint32_t mine = 0;
         for (uint32_t j = 0; j < per; ++j) { const uint32_t b = threadIdx.x * per + j; if (b < nb) mine += cnt[b]; }
@@ -297,7 +301,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_fill_sorted_kernel(GridDev g,
             if (b < nb) { start[b] = run; run += cnt[b]; }
         }
         lds_sync();
-        if (live) {
+        if (live && NERF_FILL_ABL < 2) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const uint32_t s_ = start[bin[k]] + rank[k];
@@ -310,7 +314,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_fill_sorted_kernel(GridDev g,
             }
         }
         lds_sync();
-        const int64_t n_live = (p1 - base < kSortPts ? p1 - base : kSortPts) * 8;
+        const int64_t n_live = NERF_FILL_ABL >= 1 ? 0 : (p1 - base < kSortPts ? p1 - base : kSortPts) * 8;
         for (int s_ = threadIdx.x; s_ < n_live; s_ += kBinThreads) {
             const uint32_t key = st_key[s_], b_ = key >> 16;
             const uint32_t dst = cur[b_] + ((uint32_t)s_ - start[b_]);
