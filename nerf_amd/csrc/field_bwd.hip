@@ -126,29 +126,48 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
     //   acc_c1: colour layer 1 tile id = wave             acc_x : waves 0,1: colour layer 1 tile id 4+wave
     //   acc_y : waves 0,1: sigma layer 2 tile (0, wave)            waves 2,3: colour layer 3 tile (0, wave-2)
 
-    for (int64_t bt = blockIdx.x; bt < n_btiles; bt += gridDim.x) {
-        const int64_t p_raw = bt * kBlockPts + col;
-        const bool valid = p_raw < M;
-        const int64_t p = valid ? p_raw : M - 1;
-        const PointIn q = fetch_point(src, p, true);
-        const float dsig = sel0(valid, dsigma[p]);
-        const float dr0 = sel0(valid, drgb[p * 3]), dr1 = sel0(valid, drgb[p * 3 + 1]), dr2 = sel0(valid, drgb[p * 3 + 2]);
-
-        // all of this lane's inputs are fetched up front (one exposed memory latency per block tile,
-        // not one per level): its LH*F hash-grid features and its half of the latent row
-        // (they are fetched again, from L2, right before the two places that stage them for the dW
-        // products: holding 60 more registers across the whole tile costs scratch spills instead)
-        const float* xrow = xh + p * LF + h * LHF;
-        // (an image index outside the latent table: zero latent row, no latent gradient -- as in the forward)
-        const bool n_ok = (uint64_t)q.n < (uint64_t)s.n_img;
-        const float* lrow = latent + (n_ok ? q.n : 0) * s.lat + h * s.lat_half;
+    // A tile's inputs -- the point, its two upstream gradients, this lane's LH*F hash-grid features and its half of the
+    // latent row -- are requested one tile AHEAD (right after the forward recompute of the previous tile has consumed its
+    // own): the two dependent global round trips (ray -> image index -> latent row) cost ~7 % of a tile when they were
+    // exposed at its top.  (Features and latent are fetched again, from L2, right before the two places that stage them
+    // for the dW products: holding them across the whole tile costs scratch spills instead.)
+    struct TileIn {
+        bool valid, n_ok;
+        int64_t p;
+        PointIn q;
+        float dsig, dr0, dr1, dr2;
+        const float *xrow, *lrow;
         float xf[XF], lat[24];
-        load_features<XF>(xf, xrow, LHF, LF, h, vec);
-        load_latent_half(lat, lrow, s.lat_half);
-        if (!n_ok) {
+    };
+    auto request = [&](int64_t bt, TileIn& t) {
+        const int64_t p_raw = bt * kBlockPts + col;
+        t.valid = p_raw < M;
+        t.p = t.valid ? p_raw : M - 1;
+        t.q = fetch_point(src, t.p, true);
+        t.dsig = dsigma[t.p];
+        t.dr0 = drgb[t.p * 3]; t.dr1 = drgb[t.p * 3 + 1]; t.dr2 = drgb[t.p * 3 + 2];
+        t.xrow = xh + t.p * LF + h * LHF;
+        // (an image index outside the latent table: zero latent row, no latent gradient -- as in the forward)
+        t.n_ok = (uint64_t)t.q.n < (uint64_t)s.n_img;
+        t.lrow = latent + (t.n_ok ? t.q.n : 0) * s.lat + h * s.lat_half;
+        load_features<XF>(t.xf, t.xrow, LHF, LF, h, vec);
+        load_latent_half(t.lat, t.lrow, s.lat_half);
+    };
+    TileIn nxt;
+    if ((int64_t)blockIdx.x < n_btiles) request(blockIdx.x, nxt);
+    for (int64_t bt = blockIdx.x; bt < n_btiles; bt += gridDim.x) {
+        const bool valid = nxt.valid, n_ok = nxt.n_ok;
+        const int64_t p = nxt.p;
+        const PointIn q = nxt.q;
+        const float dsig = valid ? nxt.dsig : 0.f;
+        const float dr0 = valid ? nxt.dr0 : 0.f, dr1 = valid ? nxt.dr1 : 0.f, dr2 = valid ? nxt.dr2 : 0.f;
+        const float* xrow = nxt.xrow;
+        const float* lrow = nxt.lrow;
+        float xf[XF], lat[24];
 #pragma unroll
-            for (int t = 0; t < 24; ++t) lat[t] = 0.f;
-        }
+        for (int t = 0; t < XF; ++t) xf[t] = nxt.xf[t];
+#pragma unroll
+        for (int t = 0; t < 24; ++t) lat[t] = n_ok ? nxt.lat[t] : 0.f;
         // ------------------------- forward recompute -------------------------
         f32x16 a0, a1;
         {
@@ -177,6 +196,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
         e0 = relu16(e0);
         e1 = relu16(e1);
         const f32x16 o3 = layer_64xN<kPC3>(lds + kWC3, 3, l31, h, e0, e1);
+        if (bt + gridDim.x < n_btiles) request(bt + gridDim.x, nxt);      // lands under the backward chains below
 
         // ------------------------- colour layer 3 -------------------------
         f32x16 d3 = zero16();
