@@ -233,13 +233,27 @@ constexpr int kSmallLdsFloats = 32768;   // 128 KB of the 160 KB LDS
 constexpr int kSmallMaxChunks = 16;
 constexpr int kSmallThreads = 1024;
 
+// One launch can take several levels (blockIdx.z picks one; blocks past a level's own grid leave at once): the smallest
+// levels, one chunk or two each, then run side by side instead of as three launches in a row -- which matters when they
+// have to wait for whole CUs behind the table update pass and the step ends with whatever of them is still queued.
+constexpr int kSmallSetMax = 8;
+struct SmallSet {
+    int n;
+    int level[kSmallSetMax], col[kSmallSetMax], chunk_entries[kSmallSetMax], chunks[kSmallSetMax], per_chunk[kSmallSetMax],
+        run[kSmallSetMax];
+};
+
 template <int F>
 __global__ __launch_bounds__(kSmallThreads) void scatter_small_kernel(GridDev g, NerfPointSrc src,
                                                                       const float* __restrict__ x01,
                                                                       const float* __restrict__ dfeat, int64_t M,
-                                                                      float* __restrict__ dtable, int l, int col0,
-                                                                      int64_t stride, int chunk_entries, int transpose, int run) {
+                                                                      float* __restrict__ dtable, SmallSet set,
+                                                                      int64_t stride) {
     extern __shared__ __attribute__((aligned(16))) float acc[];
+    const int z = blockIdx.z, l = set.level[z], col0 = set.col[z], chunk_entries = set.chunk_entries[z], run = set.run[z];
+    const uint32_t nbx = (uint32_t)set.per_chunk[z];        // this level's blocks per chunk (the launch may be wider)
+    if (blockIdx.x >= nbx || blockIdx.y >= (uint32_t)set.chunks[z]) return;
+    constexpr int transpose = 1;
     const uint32_t res = g.res[l], entries = g.entries[l], res2 = res * res;
     const uint32_t lo = blockIdx.y * (uint32_t)chunk_entries;
     const uint32_t n_here = min((uint32_t)chunk_entries, entries - lo);
@@ -253,7 +267,7 @@ __global__ __launch_bounds__(kSmallThreads) void scatter_small_kernel(GridDev g,
         // run of consecutive rays -- unrelated pixels, so their cells rarely coincide.
         const int64_t S = src.n_samples, n_rays = M / S, runs_per_ray = S / run;
         const int64_t total = n_rays * runs_per_ray;
-        for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (int64_t)gridDim.x * blockDim.x) {
+        for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (int64_t)nbx * blockDim.x) {
             const int64_t rblk = (int64_t)((uint64_t)v / (uint64_t)n_rays), ray = v - rblk * n_rays;
             const int64_t p0 = ray * S + rblk * run;
             uint32_t cx0 = 0xffffffffu, cy0 = 0, cz0 = 0;
@@ -314,7 +328,7 @@ __global__ __launch_bounds__(kSmallThreads) void scatter_small_kernel(GridDev g,
     // Measured better than the natural order on every level this kernel takes (also the chunked ones).
     const int64_t cols = src.mode == 1 ? src.n_samples : 64;
     const int64_t rows = M / cols, body = transpose ? rows * cols : 0;
-    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < M; v += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < M; v += (int64_t)nbx * blockDim.x) {
         int64_t p = v;
         if (v < body) { const int64_t c = (int64_t)((uint64_t)v / (uint64_t)rows); p = (v - c * rows) * cols + c; }
         float x, y, z;
@@ -348,7 +362,7 @@ __global__ __launch_bounds__(kSmallThreads) void scatter_small_kernel(GridDev g,
     __syncthreads();
     // flush; every block starts its sweep at a different place so that the blocks do not chase each other
     const uint32_t n = n_here * F;
-    const uint32_t start = (uint32_t)(((uint64_t)blockIdx.x * n) / gridDim.x);
+    const uint32_t start = (uint32_t)(((uint64_t)blockIdx.x * n) / nbx);
     float* dst = dtable + ((size_t)g.offset[l] + lo) * F;
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
         uint32_t j = i + start;
@@ -567,6 +581,32 @@ static int launch_scatter(const NerfGridCfg* grid, const NerfPointSrc* src, cons
     // (largest level first: the chunked levels need whole CUs -- 128 KB of LDS per workgroup -- and starve once the
     // table update pass fills every CU with its 16 KB workgroups; the smallest level fits beside those)
     static const int small_order = getenv("NERF_SMALL_ORDER") ? atoi(getenv("NERF_SMALL_ORDER")) : 1;
+    static const bool merge_small = getenv("NERF_SMALL_MERGE") ? atoi(getenv("NERF_SMALL_MERGE")) != 0 : true;
+    SmallSet merged = {};
+    auto launch_small = [&](const SmallSet& ss) -> int {
+        int gx = 1, gy = 1, lds_bytes = 0;
+        for (int k = 0; k < ss.n; ++k) {
+            gx = ss.per_chunk[k] > gx ? ss.per_chunk[k] : gx;
+            gy = ss.chunks[k] > gy ? ss.chunks[k] : gy;
+            const int b = ss.chunk_entries[k] * F * (int)sizeof(float);
+            lds_bytes = b > lds_bytes ? b : lds_bytes;
+        }
+        const dim3 nb((unsigned)gx, (unsigned)gy, (unsigned)ss.n);
+#define LAUNCH_SMALL(FF)                                                                                                  \
+        do {                                                                                                              \
+            auto kern = scatter_small_kernel<FF>;                                                                         \
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
+            if (e != hipSuccess) { nerf_set_error("scatter: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }   \
+            kern<<<nb, kSmallThreads, lds_bytes, st>>>(g, s, x01, dfeat, n_points, dtable, ss, stride);                   \
+        } while (0)
+        switch (F) {
+            case 1: LAUNCH_SMALL(1); break;
+            case 2: LAUNCH_SMALL(2); break;
+            default: LAUNCH_SMALL(4); break;
+        }
+#undef LAUNCH_SMALL
+        return 0;
+    };
     for (int ii = 0; ii < set.count; ++ii) {
         const int i = small_order ? set.count - 1 - ii : ii;
         const int l = set.level[i], col = col0 + i * F;
@@ -585,27 +625,19 @@ static int launch_scatter(const NerfGridCfg* grid, const NerfPointSrc* src, cons
                 run *= 2;
         const int chunks = (int)ceil_div64(floats, kSmallLdsFloats);
         const int chunk_entries = (int)ceil_div64(grid->entries[l], chunks);
-        const int lds_bytes = chunk_entries * F * (int)sizeof(float);
         int64_t per_chunk = kNumCU / chunks;
         const int64_t want = ceil_div64(n_points, kSmallThreads);
         if (per_chunk > want) per_chunk = want;
         if (per_chunk < 1) per_chunk = 1;
-        const dim3 nb((unsigned)per_chunk, (unsigned)chunks);
-#define LAUNCH_SMALL(FF)                                                                                                  \
-        do {                                                                                                              \
-            auto kern = scatter_small_kernel<FF>;                                                                         \
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
-            if (e != hipSuccess) { nerf_set_error("scatter: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }   \
-            kern<<<nb, kSmallThreads, lds_bytes, st>>>(g, s, x01, dfeat, n_points, dtable, l, col, stride, chunk_entries,  \
-                                                       1, run);                                           \
-        } while (0)
-        switch (F) {
-            case 1: LAUNCH_SMALL(1); break;
-            case 2: LAUNCH_SMALL(2); break;
-            default: LAUNCH_SMALL(4); break;
-        }
-#undef LAUNCH_SMALL
+        // the levels of one or two chunks share a launch (issued after the chunked ones), the others get their own
+        SmallSet one = {};
+        SmallSet& dst = (chunks <= 2 && merged.n < kSmallSetMax && merge_small) ? merged : one;
+        const int k = dst.n++;
+        dst.level[k] = l; dst.col[k] = col; dst.chunk_entries[k] = chunk_entries; dst.chunks[k] = chunks;
+        dst.per_chunk[k] = (int)per_chunk; dst.run[k] = run;
+        if (&dst == &one) { const int rc = launch_small(one); if (rc) return rc; }
     }
+    if (merged.n > 0) { const int rc = launch_small(merged); if (rc) return rc; }
     if (plan.count > 0) {
         const dim3 nb((unsigned)ceil_div64(n_points * 8 * F, 256), (unsigned)plan.count);
         switch (F) {

@@ -11,6 +11,9 @@ from . import parallel
 from ._lib import NerfLevelSet, check, lib, ptr, stream
 
 
+SMALL_TENSORS_ON_SIDE_STREAM = os.environ.get('NERF_SMALL_ADAM_SIDE', '1') != '0'
+
+
 class TablePipeline(object):
     """Per-level pipeline for the hash-table gradient: scatter(level group) on the main stream ->
     [all-reduce of that slice, when distributed] -> Adam on that slice on a side stream.
@@ -277,42 +280,27 @@ class FusedAdam(torch.optim.Optimizer):
         self._skip_ptr = ptr(flag) if flag is not None else None
         if self._flag_reads:
             self._collect_flags()
+        # One GPU with the binned table update: the small tensors (MLPs, latent table) take their Adam step on the side
+        # stream BESIDE the table passes instead of after them (three 7 us launches at the very end of the step otherwise)
+        pipe = self._pipeline
+        early = (pipe is not None and bool(pipe.binned_levels) and pipe.pending and self._sharding is None
+                 and SMALL_TENSORS_ON_SIDE_STREAM)
+        if early:
+            if pipe.side is None:
+                pipe.side = torch.cuda.Stream()
+            ready = torch.cuda.Event()
+            ready.record()          # their gradients (and, under data parallelism, the all-reduce of them) are complete
+            with torch.cuda.stream(pipe.side):
+                pipe.side.wait_event(ready)
+                for group in self.param_groups:
+                    for p in group['params']:
+                        if p is not self._table_param:
+                            self._step_param(group, p)
         for group in self.param_groups:
-            b1, b2 = group['betas']
             for p in group['params']:
-                if p.grad is None or p.numel() == 0:
+                if early and p is not self._table_param:
                     continue
-                st = self.state[p]
-                if not st:
-                    st['step'] = 0
-                    st['exp_avg'] = torch.zeros_like(p)
-                    st['exp_avg_sq'] = torch.zeros_like(p)
-                    # The moments are first used on the pipeline's side stream, which only waits for backward events
-                    # recorded BEFORE these fills were issued: without this one-time wait the fills can land after the
-                    # first Adam pass and wipe its moments (v = 0 with m != 0 then divides by eps on the next step).
-                    torch.cuda.current_stream().synchronize()
-                st['step'] += 1
-                pipe = self._pipeline
-                if p is self._table_param and pipe is not None and pipe.binned_levels:
-                    self._binned_table_step(p, st, group, b1, b2, pipe)
-                if p is self._table_param and self._sharding is not None:
-                    # level-sharded table: only the owned levels have (complete) gradients and moments here
-                    self._sharding.dirty = True
-                    if pipe.pending:
-                        self._pipelined_table_step(p, st, group, b1, b2, pipe)
-                    continue
-                if pipe is not None and p is self._table_param and pipe.pending:
-                    self._pipelined_table_step(p, st, group, b1, b2, pipe)
-                    continue
-                if pipe is not None and p is self._table_param and pipe.binned_levels:
-                    # no backward reached the table this step: the remaining (small) levels still take their Adam step
-                    flat_p, flat_g = p.view(-1), p.grad.view(-1)
-                    flat_m, flat_v = st['exp_avg'].view(-1), st['exp_avg_sq'].view(-1)
-                    for (l0, cnt) in pipe.groups:
-                        a, b = pipe.slices[l0]
-                        self._adam(flat_p[a:b], flat_g[a:b], flat_m[a:b], flat_v[a:b], group, b1, b2, st['step'])
-                    continue
-                self._adam(p, p.grad, st['exp_avg'], st['exp_avg_sq'], group, b1, b2, st['step'])
+                self._step_param(group, p)
         model = getattr(self, '_model', None)
         self._cleared_at = model.backward_count if model is not None else None
         if flag is not None:
@@ -322,6 +310,42 @@ class FusedAdam(torch.optim.Optimizer):
             ev.record()
             self._flag_reads.append((ev, host))
             self.skip_flag = None
+
+    def _step_param(self, group, p):
+        b1, b2 = group['betas']
+        if p.grad is None or p.numel() == 0:
+            return
+        st = self.state[p]
+        if not st:
+            st['step'] = 0
+            st['exp_avg'] = torch.zeros_like(p)
+            st['exp_avg_sq'] = torch.zeros_like(p)
+            # The moments are first used on the pipeline's side stream, which only waits for backward events
+            # recorded BEFORE these fills were issued: without this one-time wait the fills can land after the
+            # first Adam pass and wipe its moments (v = 0 with m != 0 then divides by eps on the next step).
+            torch.cuda.current_stream().synchronize()
+        st['step'] += 1
+        pipe = self._pipeline
+        if p is self._table_param and pipe is not None and pipe.binned_levels:
+            self._binned_table_step(p, st, group, b1, b2, pipe)
+        if p is self._table_param and self._sharding is not None:
+            # level-sharded table: only the owned levels have (complete) gradients and moments here
+            self._sharding.dirty = True
+            if pipe.pending:
+                self._pipelined_table_step(p, st, group, b1, b2, pipe)
+            return
+        if pipe is not None and p is self._table_param and pipe.pending:
+            self._pipelined_table_step(p, st, group, b1, b2, pipe)
+            return
+        if pipe is not None and p is self._table_param and pipe.binned_levels:
+            # no backward reached the table this step: the remaining (small) levels still take their Adam step
+            flat_p, flat_g = p.view(-1), p.grad.view(-1)
+            flat_m, flat_v = st['exp_avg'].view(-1), st['exp_avg_sq'].view(-1)
+            for (l0, cnt) in pipe.groups:
+                a, b = pipe.slices[l0]
+                self._adam(flat_p[a:b], flat_g[a:b], flat_m[a:b], flat_v[a:b], group, b1, b2, st['step'])
+            return
+        self._adam(p, p.grad, st['exp_avg'], st['exp_avg_sq'], group, b1, b2, st['step'])
 
     def _adam(self, p, g, m, v, group, b1, b2, step):
         check(lib().nerf_adam_step_guarded(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), group['lr'], b1, b2, group['eps'],
