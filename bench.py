@@ -92,9 +92,12 @@ def train_step(model, renderer, loader, opt, n_rays, it, world):
     from nerf_amd import helpers, parallel
     opt.zero_grad()
     n, h, w, K, E, rgb_gt, color_bg, _ = loader.get_random_batch(n_rays)
-    rgb, weights, zs, _ = renderer.render(n, h, w, K, E, color_bg)
     lam_dist = 10 ** (it / 10000 * 3 - 5)            # trainer.py:160 with lambda 1e-5 -> 1e-2 over 10k iters
-    loss, _ = helpers.fused_train_loss(rgb, rgb_gt, weights, zs, lam_dist, 1e-1)
+    if os.environ.get('NERF_FUSED_TAIL', '1') != '0':
+        loss = renderer.render_loss(n, h, w, K, E, color_bg, rgb_gt, lam_dist, 1e-1)[0]   # what Trainer.train_step calls
+    else:
+        rgb, weights, zs, _ = renderer.render(n, h, w, K, E, color_bg)
+        loss, _ = helpers.fused_train_loss(rgb, rgb_gt, weights, zs, lam_dist, 1e-1)
     loss.backward()
     opt.skip_flag = loss.nonfinite_flag        # Trainer.train_epoch's non-finite guard (device side, no sync)
     if world > 1:

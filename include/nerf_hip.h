@@ -250,6 +250,25 @@ int nerf_losses(const float* image, const float* gt, const float* weights, const
                 int n_samples, float lam_dist, float lam_depth, float grad_scale, int sorted, double* sums,
                 float* dimage, float* dweights, void* stream);
 
+/* ---- compositing + losses in one launch for the training step, and the backward of both in one more ----
+ * nerf_composite_fwd followed by nerf_losses (sorted form, grad_scale 1) / the gradients nerf_losses would write followed
+ * by nerf_composite_bwd, with the same arithmetic (renderer.py:71-85,180-182; helpers.py:21-32; trainer.py:153-169 and
+ * the autograd of :134): image, weights, zlog_s, dsigma and drgb equal the separate entry points' bit for bit.
+ * sums: NERF_LOSS_SUMS_DOUBLES doubles, written by the call: [0..4] as nerf_losses, [5] the non-finite flag of the total,
+ * [8 ..] one row of four partial sums per workgroup (added up in a fixed order: the totals are reproducible run to run).
+ * loss_out: six floats: loss_rgb, loss_dist, loss_depth, mse, the total and the flag.
+ * dout (nullable = 1): device scalar, d(objective)/d(total loss) -- what autograd hands to backward(). */
+#define NERF_LOSS_MAX_ROWS 1024
+#define NERF_LOSS_SUMS_DOUBLES (8 + 4 * NERF_LOSS_MAX_ROWS)
+int nerf_composite_loss_fwd(const float* sigma, const float* rgb, const float* z, const float* zlog, const float* bg,
+                            const float* gt /*[N,3]*/, int64_t n_rays, int n_samples, float zlog_lo, float zlog_range,
+                            float lam_dist, float lam_depth, float* image, float* invdepth, float* weights,
+                            float* zlog_s /*nullable*/, double* sums /*[NERF_LOSS_SUMS_DOUBLES]*/, float* loss_out /*[6]*/,
+                            void* stream);
+int nerf_composite_loss_bwd(const float* sigma, const float* rgb, const float* zlog, const float* bg, const float* gt,
+                            const float* image, const float* dout, int64_t n_rays, int n_samples, float zlog_lo,
+                            float zlog_range, float lam_dist, float lam_depth, float* dsigma, float* drgb, void* stream);
+
 /* ---- optimizer: torch.optim.Adam as configured at train.py:84-88 (dense, L2 weight decay) ---- */
 /* step is the 1-based step count; when zero_grad != 0 the gradient is cleared in the same pass. */
 int nerf_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t count, float lr, float beta1,

@@ -82,6 +82,8 @@ SIGNATURES = {
     'nerf_composite_fwd': (_I, [_P, _P, _P, _P, _P, _I64, _I, _F, _F, _P, _P, _P, _P, _P]),
     'nerf_composite_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I64, _I, _P, _P, _P]),
     'nerf_losses': (_I, [_P, _P, _P, _P, _I64, _I, _F, _F, _F, _I, _P, _P, _P, _P]),
+    'nerf_composite_loss_fwd': (_I, [_P, _P, _P, _P, _P, _P, _I64, _I, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
+    'nerf_composite_loss_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, _I, _F, _F, _F, _F, _P, _P, _P]),
     'nerf_adam_step': (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _I64, _F, _I, _P]),
     'nerf_adam_step_guarded': (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _I64, _F, _I, _P, _P]),
     'nerf_table_update_binned_guarded': (_I, [_G, _LS, _I64, _P, _I64, _P, _P, _P, _F, _F, _F, _F, _F, _I64, _F, _P, _P]),

@@ -586,6 +586,279 @@ __global__ __launch_bounds__(256) void losses_kernel(const float* __restrict__ i
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// R10 + R11 fused for the training step: compositing, the three losses and (second kernel) the backward of both.
+// The arithmetic is composite_fwd_kernel's, losses_kernel's (sorted form) and composite_bwd_kernel's, operation for
+// operation -- the same image, weights and gradients bit for bit; only the order in which the workgroups add their loss
+// totals differs.  What goes away: the weights / zlog_s round trip through HBM between the kernels, dimage / dweights
+// altogether, and five small launches (zeroing, fp64 -> fp32 copy, two multiplies by d(loss), the separate compositing).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void composite_loss_fwd_kernel(
+    const float* __restrict__ sigma, const float* __restrict__ rgb, const float* __restrict__ z, const float* __restrict__ zlog,
+    const float* __restrict__ bg, const float* __restrict__ gt, int64_t n_rays, int S, float zlog_lo, float zlog_range,
+    float* __restrict__ image, float* __restrict__ invdepth, float* __restrict__ weights,
+    float* __restrict__ zlog_s, double* __restrict__ partials) {
+    __shared__ float s_sig[kRaysPerBlock][kMaxS];
+    __shared__ float s_zl[kRaysPerBlock][kMaxS];
+    __shared__ float s_z[kRaysPerBlock][kMaxS];
+    __shared__ float s_rgb[kRaysPerBlock][kMaxS * 3];
+    __shared__ double s_part[kRaysPerBlock][4];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int C = (S + kWave - 1) / kWave;
+    const double inv_n = 1.0 / (double)n_rays;
+    const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
+    double l_rgb = 0, l_mse = 0, l_dist = 0, l_depth = 0;
+    for (int64_t base = (int64_t)blockIdx.x * kRaysPerBlock; base < n_rays; base += (int64_t)gridDim.x * kRaysPerBlock) {
+        int64_t ray = base + wv;
+        const bool live = ray < n_rays;
+        if (!live) ray = n_rays - 1;
+        __syncthreads();        // the previous round's readers of this wave's rows are done
+        load_row(s_sig[wv], sigma + ray * S, S, lane);
+        load_row(s_zl[wv], zlog + ray * S, S, lane);
+        load_row(s_z[wv], z + ray * S, S, lane);
+        load_row(s_rgb[wv], rgb + ray * S * 3, S * 3, lane);
+        __syncthreads();
+        const float *sig = s_sig[wv], *zl = s_zl[wv], *zz = s_z[wv], *col = s_rgb[wv];
+        // ---- composite_fwd_kernel ----
+        float alpha[kMaxC];
+        double om_local[kMaxC];
+        double prod = 1.0;
+#pragma unroll
+        for (int c = 0; c < kMaxC; ++c) {
+            int i = lane * C + c;
+            alpha[c] = 0.f;
+            om_local[c] = prod;
+            if (c < C && i < S) {
+                float delta = (i < S - 1) ? (zl[i + 1] - zl[i]) : 0.f;
+                float a = 1.f - expf(-sig[i] * delta);
+                alpha[c] = a;
+                prod *= (double)(1.f - a);
+            }
+        }
+        double before = wave_excl_prod(prod, lane);
+        double ar = 0, ag = 0, ab = 0, ainv = 0, aw = 0;
+        float wgt[kMaxC], ss[kMaxC];
+#pragma unroll
+        for (int c = 0; c < kMaxC; ++c) {
+            int i = lane * C + c;
+            wgt[c] = 0.f;
+            ss[c] = 0.f;
+            if (c < C && i < S) {
+                wgt[c] = alpha[c] * (float)(before * om_local[c]);
+                ss[c] = (zl[i] - zlog_lo) / zlog_range;
+                ar += (double)(wgt[c] * col[i * 3]);
+                ag += (double)(wgt[c] * col[i * 3 + 1]);
+                ab += (double)(wgt[c] * col[i * 3 + 2]);
+                ainv += (double)(wgt[c] / zz[i]);
+                aw += (double)wgt[c];
+            }
+        }
+        ar = wave_sum(ar); ag = wave_sum(ag); ab = wave_sum(ab); ainv = wave_sum(ainv); aw = wave_sum(aw);
+        const float rest = 1.f - (float)aw;
+        const float im0 = (float)ar + rest * b0, im1 = (float)ag + rest * b1, im2 = (float)ab + rest * b2;
+        if (live) {
+#pragma unroll
+            for (int c = 0; c < kMaxC; ++c) {
+                int i = lane * C + c;
+                if (c < C && i < S) {
+                    weights[ray * S + i] = wgt[c];
+                    if (zlog_s) zlog_s[ray * S + i] = ss[c];
+                }
+            }
+            if (lane == 0) {
+                image[ray * 3] = im0; image[ray * 3 + 1] = im1; image[ray * 3 + 2] = im2;
+                invdepth[ray] = (float)ainv;
+            }
+        }
+        // ---- losses_kernel (sorted form) on the same registers ----
+        double r_rgb = 0, r_mse = 0, r_dist = 0, r_depth = 0;
+        if (lane < 3) {
+            const float im = lane == 0 ? im0 : (lane == 1 ? im1 : im2);
+            float d = im - gt[ray * 3 + lane];
+            float ad = fabsf(d);
+            const float hd = 0.1f;
+            r_rgb = ad <= hd ? 0.5 * (double)d * d : (double)hd * ((double)ad - 0.5 * hd);
+            r_mse = (double)d * d;
+        }
+        double lw = 0, lws = 0;
+#pragma unroll
+        for (int c = 0; c < kMaxC; ++c) {
+            int i = lane * C + c;
+            if (c < C && i < S) { lw += (double)wgt[c]; lws += (double)wgt[c] * (double)ss[c]; }
+        }
+        double pw = wave_excl_sum(lw, lane), pws = wave_excl_sum(lws, lane);
+#pragma unroll
+        for (int c = 0; c < kMaxC; ++c) {
+            int i = lane * C + c;
+            if (c < C && i < S) {
+                double wi = wgt[c], si = ss[c];
+                r_dist += 2.0 * wi * (si * pw - pws);
+                r_depth += wi * (1.0 - si);
+                pw += wi;
+                pws += wi * si;
+            }
+        }
+        if (live) { l_rgb += r_rgb; l_mse += r_mse; l_dist += r_dist; l_depth += r_depth; }
+    }
+    l_rgb = wave_sum(l_rgb); l_mse = wave_sum(l_mse); l_dist = wave_sum(l_dist); l_depth = wave_sum(l_depth);
+    if (lane == 0) {
+        s_part[wv][0] = l_rgb * inv_n / 3.0;
+        s_part[wv][1] = l_dist * inv_n;
+        s_part[wv][2] = l_depth * inv_n / (double)S;
+        s_part[wv][3] = l_mse * inv_n / 3.0;
+    }
+    __syncthreads();
+    // one row of four partial sums per workgroup, plain stores: composite_loss_finish_kernel adds the rows up in a fixed
+    // order (no same-line fp64 atomics from a thousand workgroups, no device-scope fence, and a reproducible total)
+    if (threadIdx.x < 4)
+        partials[(int64_t)blockIdx.x * 4 + threadIdx.x] =
+            s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
+}
+
+// sums[0..5] and loss_out[0..5] from the per-workgroup rows: one workgroup, a fixed-shape tree
+__global__ __launch_bounds__(256) void composite_loss_finish_kernel(const double* __restrict__ partials, int n_rows,
+                                                                    float lam_dist, float lam_depth,
+                                                                    double* __restrict__ sums, float* __restrict__ loss_out) {
+    __shared__ double s_acc[256][4];
+    double a[4] = {0, 0, 0, 0};
+    for (int r = threadIdx.x; r < n_rows; r += 256)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] += partials[(int64_t)r * 4 + k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s_acc[threadIdx.x][k] = a[k];
+    __syncthreads();
+    for (int step = 128; step > 0; step >>= 1) {
+        if ((int)threadIdx.x < step)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s_acc[threadIdx.x][k] += s_acc[threadIdx.x + step][k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double t0 = s_acc[0][0], t1 = s_acc[0][1], t2 = s_acc[0][2], t3 = s_acc[0][3];
+        const double total = t0 + (double)lam_dist * t1 + (double)lam_depth * t2;
+        const bool bad = !(fabs(total) <= 1.7976931348623157e308);
+        sums[0] = t0; sums[1] = t1; sums[2] = t2; sums[3] = t3; sums[4] = total; sums[5] = bad ? 1.0 : 0.0;
+        loss_out[0] = (float)t0; loss_out[1] = (float)t1; loss_out[2] = (float)t2; loss_out[3] = (float)t3;
+        loss_out[4] = (float)total; loss_out[5] = bad ? 1.f : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void composite_loss_bwd_kernel(
+    const float* __restrict__ sigma, const float* __restrict__ rgb, const float* __restrict__ zlog, const float* __restrict__ bg,
+    const float* __restrict__ gt, const float* __restrict__ image, const float* __restrict__ dout, int64_t n_rays, int S,
+    float zlog_lo, float zlog_range, float lam_dist, float lam_depth, float* __restrict__ dsigma, float* __restrict__ drgb) {
+    __shared__ float s_sig[kRaysPerBlock][kMaxS];
+    __shared__ float s_zl[kRaysPerBlock][kMaxS];
+    __shared__ float s_rgb[kRaysPerBlock][kMaxS * 3];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wv;
+    const bool live = ray < n_rays;
+    if (!live) ray = n_rays - 1;
+    const int C = (S + kWave - 1) / kWave;
+    load_row(s_sig[wv], sigma + ray * S, S, lane);
+    load_row(s_zl[wv], zlog + ray * S, S, lane);
+    load_row(s_rgb[wv], rgb + ray * S * 3, S * 3, lane);
+    __syncthreads();
+    const float *sig = s_sig[wv], *zl = s_zl[wv];
+    float* col = s_rgb[wv];
+    const float up = dout ? dout[0] : 1.f;
+    const double inv_n = 1.0 / (double)n_rays;
+    // d(loss)/d(image): Huber gradient, as losses_kernel writes it (grad_scale = 1), times the upstream gradient
+    float gi[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float d = image[ray * 3 + k] - gt[ray * 3 + k];
+        float ad = fabsf(d);
+        const float hd = 0.1f;
+        float gr = ad <= hd ? d : (d > 0 ? hd : -hd);
+        gi[k] = (1.0f * gr * (float)(inv_n / 3.0)) * up;
+    }
+    const float gi0 = gi[0], gi1 = gi[1], gi2 = gi[2];
+    const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
+    float alpha[kMaxC], delta[kMaxC];
+    double om_local[kMaxC];
+    double prod = 1.0;
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c) {
+        int i = lane * C + c;
+        alpha[c] = 0.f;
+        delta[c] = 0.f;
+        om_local[c] = prod;
+        if (c < C && i < S) {
+            float d = (i < S - 1) ? (zl[i + 1] - zl[i]) : 0.f;
+            float a = 1.f - expf(-sig[i] * d);
+            alpha[c] = a;
+            delta[c] = d;
+            prod *= (double)(1.f - a);
+        }
+    }
+    double before = wave_excl_prod(prod, lane);
+    float wgt[kMaxC], ss[kMaxC], g[kMaxC];
+    double lw = 0, lws = 0;
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c) {
+        int i = lane * C + c;
+        wgt[c] = 0.f;
+        ss[c] = 0.f;
+        if (c < C && i < S) {
+            wgt[c] = alpha[c] * (float)(before * om_local[c]);
+            ss[c] = (zl[i] - zlog_lo) / zlog_range;
+            lw += (double)wgt[c];
+            lws += (double)wgt[c] * (double)ss[c];
+        }
+    }
+    // d(loss)/d(weights): losses_kernel's sorted form
+    double pw = wave_excl_sum(lw, lane), pws = wave_excl_sum(lws, lane);
+    const double tw = wave_sum(lw), tws = wave_sum(lws);
+    const float cd = 1.0f * lam_dist * (float)inv_n;
+    const float cz = 1.0f * lam_depth * (float)(inv_n / (double)S);
+    double gw_local = 0.0;
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c) {
+        int i = lane * C + c;
+        g[c] = 0.f;
+        if (c < C && i < S) {
+            const double wi = wgt[c], si = ss[c];
+            const double aw = tw - pw - wi, aws = tws - pws - wi * si;      // strictly after i
+            const float gdw = (float)(2.0 * (si * pw - pws + aws - si * aw));
+            const float dw = (cd * gdw + cz * (1.f - ss[c])) * up;
+            pw += wi;
+            pws += wi * si;
+            g[c] = dw + gi0 * (col[i * 3] - b0) + gi1 * (col[i * 3 + 1] - b1) + gi2 * (col[i * 3 + 2] - b2);
+            gw_local += (double)g[c] * (double)wgt[c];
+        }
+    }
+    // ---- composite_bwd_kernel from here ----
+    double after = wave_excl_suffix_sum(gw_local, lane);
+    double suffix = after;
+    float ds[kMaxC];
+#pragma unroll
+    for (int c = kMaxC - 1; c >= 0; --c) {
+        int i = lane * C + c;
+        ds[c] = 0.f;
+        if (c < C && i < S) {
+            double t_next = before * om_local[c] * (double)(1.f - alpha[c]);
+            ds[c] = delta[c] * (float)((double)g[c] * t_next - suffix);
+            suffix += (double)g[c] * (double)wgt[c];
+        }
+    }
+    __syncthreads();  // all reads of col[] done before it is overwritten with drgb
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c) {
+        int i = lane * C + c;
+        if (c < C && i < S) {
+            s_sig[wv][i] = ds[c];
+            col[i * 3] = wgt[c] * gi0;
+            col[i * 3 + 1] = wgt[c] * gi1;
+            col[i * 3 + 2] = wgt[c] * gi2;
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    for (int i = lane; i < S; i += kWave) dsigma[ray * S + i] = s_sig[wv][i];
+    for (int i = lane; i < S * 3; i += kWave) drgb[ray * S * 3 + i] = col[i];
+}
+
 // inference.py:97-105: one-hot of the first sample whose running weight sum reaches thresh
 __global__ __launch_bounds__(256) void cum_thresh_kernel(const float* __restrict__ weights, int64_t n_rays, int S,
                                                          float thresh, float* __restrict__ out) {
@@ -768,6 +1041,33 @@ int nerf_losses(const float* image, const float* gt, const float* weights, const
     losses_kernel<<<(unsigned)(loss_blocks < loss_cap ? loss_blocks : loss_cap), 256, 0, S_(stream)>>>(
         image, gt, weights, zlog_s, n_rays, n_samples, lam_dist, lam_depth, grad_scale, sorted, sums, dimage, dweights);
     return nerf_launch_status("nerf_losses");
+}
+
+int nerf_composite_loss_fwd(const float* sigma, const float* rgb, const float* z, const float* zlog, const float* bg,
+                            const float* gt, int64_t n_rays, int n_samples, float zlog_lo, float zlog_range, float lam_dist,
+                            float lam_depth, float* image, float* invdepth, float* weights, float* zlog_s, double* sums,
+                            float* loss_out, void* stream) {
+    NERF_REQUIRE(sigma && rgb && z && zlog && bg && gt && image && invdepth && weights && sums && loss_out, "null pointer");
+    NERF_REQUIRE(check_ray_args(n_rays, n_samples) != 2, "n_samples must be in [1, 512]");
+    NERF_REQUIRE(n_rays > 0, "need at least one ray");
+    NERF_REQUIRE((((uintptr_t)sums) & 7) == 0, "sums must be 8-byte aligned");
+    const int64_t blocks = ceil_div64(n_rays, kRaysPerBlock);
+    const int n_wg = (int)(blocks < NERF_LOSS_MAX_ROWS ? blocks : NERF_LOSS_MAX_ROWS);
+    composite_loss_fwd_kernel<<<(unsigned)n_wg, 256, 0, S_(stream)>>>(sigma, rgb, z, zlog, bg, gt, n_rays, n_samples, zlog_lo,
+                                                                    zlog_range, image, invdepth, weights, zlog_s, sums + 8);
+    composite_loss_finish_kernel<<<1, 256, 0, S_(stream)>>>(sums + 8, n_wg, lam_dist, lam_depth, sums, loss_out);
+    return nerf_launch_status("nerf_composite_loss_fwd");
+}
+
+int nerf_composite_loss_bwd(const float* sigma, const float* rgb, const float* zlog, const float* bg, const float* gt,
+                            const float* image, const float* dout, int64_t n_rays, int n_samples, float zlog_lo,
+                            float zlog_range, float lam_dist, float lam_depth, float* dsigma, float* drgb, void* stream) {
+    NERF_REQUIRE(sigma && rgb && zlog && bg && gt && image && dsigma && drgb, "null pointer");
+    NERF_REQUIRE(check_ray_args(n_rays, n_samples) != 2, "n_samples must be in [1, 512]");
+    if (n_rays <= 0) return n_rays == 0 ? 0 : NERF_EINVAL;
+    composite_loss_bwd_kernel<<<(unsigned)ceil_div64(n_rays, kRaysPerBlock), 256, 0, S_(stream)>>>(
+        sigma, rgb, zlog, bg, gt, image, dout, n_rays, n_samples, zlog_lo, zlog_range, lam_dist, lam_depth, dsigma, drgb);
+    return nerf_launch_status("nerf_composite_loss_bwd");
 }
 
 int nerf_cum_weights_thresh(const float* weights, int64_t n_rays, int n_samples, float thresh, float* out, void* stream) {

@@ -55,6 +55,47 @@ class _CompositeFn(torch.autograd.Function):
         return dsig, drgb, None, None, None, None, None
 
 
+class _CompositeLossFn(torch.autograd.Function):
+    """_CompositeFn followed by helpers._LossFn ('total') as ONE kernel, and the backward of both as one more
+    (nerf_composite_loss_fwd / _bwd): the training step's tail without the weights / zlog_s round trip, without dimage /
+    dweights and without five small launches.  Only the loss is differentiable; image, weights, ... come out detached."""
+
+    @staticmethod
+    def forward(ctx, sigmas, rgbs, z_vals, z_vals_log, bg, gt, lo, rng, lam_dist, lam_depth):
+        sig, rgb, z, zl, bgc, g = f32(sigmas), f32(rgbs), f32(z_vals), f32(z_vals_log), f32(bg), f32(gt)
+        N, S = sig.shape
+        dev = sig.device
+        image = torch.empty(N, 3, device=dev)
+        invdepth = torch.empty(N, device=dev)
+        weights = torch.empty(N, S, device=dev)
+        zlog_s = torch.empty(N, S, device=dev)
+        sums = torch.empty(8 + 4 * 1024, device=dev, dtype=torch.float64)     # NERF_LOSS_SUMS_DOUBLES
+        out = torch.empty(6, device=dev)
+        check(lib().nerf_composite_loss_fwd(ptr(sig), ptr(rgb), ptr(z), ptr(zl), ptr(bgc), ptr(g), N, S, lo, rng, lam_dist,
+                                            lam_depth, ptr(image), ptr(invdepth), ptr(weights), ptr(zlog_s), ptr(sums),
+                                            ptr(out), stream()), 'nerf_composite_loss_fwd')
+        ctx.save_for_backward(sig, rgb, zl, bgc, g, image)
+        ctx.consts = (lo, rng, lam_dist, lam_depth)
+        loss, parts, flag = out[4], out[:4], sums[5:6]
+        ctx.mark_non_differentiable(parts, flag, image, invdepth, weights, zlog_s)
+        ctx.set_materialize_grads(False)
+        return loss, parts, flag, image, invdepth, weights, zlog_s
+
+    @staticmethod
+    def backward(ctx, dout, *_unused):
+        if dout is None:
+            return (None,) * 10
+        sig, rgb, zl, bgc, g, image = ctx.saved_tensors
+        lo, rng, lam_dist, lam_depth = ctx.consts
+        N, S = sig.shape
+        dsig = torch.empty_like(sig)
+        drgb = torch.empty_like(rgb)
+        check(lib().nerf_composite_loss_bwd(ptr(sig), ptr(rgb), ptr(zl), ptr(bgc), ptr(g), ptr(image), ptr(f32(dout)), N, S,
+                                            lo, rng, lam_dist, lam_depth, ptr(dsig), ptr(drgb), stream()),
+              'nerf_composite_loss_bwd')
+        return (dsig, drgb) + (None,) * 8
+
+
 class NerfRenderer(nn.Module):
     def __init__(self, model, inner_bound, outer_bound, z_bounds, steps_firstpass, steps_importance, alpha_importance):
         super().__init__()
@@ -207,7 +248,7 @@ class NerfRenderer(nn.Module):
                                         len(self.steps_firstpass), ptr(zlog_f), ptr(z_f), stream()), 'nerf_coarse_to_fine')
         return zlog_f, z_f
 
-    def render(self, n, h, w, K, E, bg_color, noise=None, generator=None, aux=True):
+    def render(self, n, h, w, K, E, bg_color, noise=None, generator=None, aux=True, train_loss=None):
         """renderer.py:170-194.  ``aux=False`` (inference only, no grad): the per-sample aux outputs ``xyzs`` and
         ``x_hashtable`` are not produced (172 B per sample that render_image never reads)."""
         rays_o, rays_d = self.get_rays(h, w, K, E)
@@ -235,7 +276,15 @@ class NerfRenderer(nn.Module):
             x_hashtable = aux_outputs_net['x_hashtable']
         lo = m.log10(self.z_bounds[0])
         rng = m.log10(self.z_bounds[-1]) - lo
-        image, invdepth, weights, z_vals_log_s = _CompositeFn.apply(sigmas, rgbs, z_vals, z_vals_log, bg_color, lo, rng)
+        loss = None
+        if train_loss is not None:
+            rgb_gt, lam_dist, lam_depth = train_loss
+            total, parts, flag, image, invdepth, weights, z_vals_log_s = _CompositeLossFn.apply(
+                sigmas, rgbs, z_vals, z_vals_log, bg_color, rgb_gt, lo, rng, float(lam_dist), float(lam_depth))
+            total.nonfinite_flag = flag
+            loss = (total, parts)
+        else:
+            image, invdepth, weights, z_vals_log_s = _CompositeFn.apply(sigmas, rgbs, z_vals, z_vals_log, bg_color, lo, rng)
 
         # auxilary outputs that may be useful for inference of analysis, but not used in training
         aux_outputs = {}
@@ -246,4 +295,13 @@ class NerfRenderer(nn.Module):
         aux_outputs['rgbs'] = rgbs.detach()
         aux_outputs['xyzs'] = xyzs.detach() if xyzs is not None else None
         aux_outputs['x_hashtable'] = x_hashtable
+        if loss is not None:
+            return loss[0], loss[1], image, weights, z_vals_log_s, aux_outputs
         return image, weights, z_vals_log_s, aux_outputs
+
+    def render_loss(self, n, h, w, K, E, bg_color, rgb_gt, lam_dist, lam_depth, noise=None, generator=None):
+        """render() + helpers.fused_train_loss() (trainer.py:149-169) with compositing and the losses in one kernel and
+        their backward in one more.  Returns (loss, parts[4] = loss_rgb, loss_dist, loss_depth, mse, image, weights,
+        z_vals_log_s, aux); only `loss` carries a gradient (use render() + the helpers for anything else);
+        ``loss.nonfinite_flag`` as in helpers.fused_train_loss."""
+        return self.render(n, h, w, K, E, bg_color, noise=noise, generator=generator, train_loss=(rgb_gt, lam_dist, lam_depth))

@@ -151,10 +151,14 @@ class Trainer(object):
     def train_step(self):
         self.model.train()
         n, h, w, K, E, rgb_gt, color_bg, _ = self.dataloader.get_random_batch(self.n_rays)
-        rgb, weights, z_vals_log_s, aux_outputs = self.renderer.render(n, h, w, K, E, color_bg, noise=self.noise)
-
         dist_scalar, depth_scalar = self.loss_lambdas()
-        loss, parts = helpers.fused_train_loss(rgb, rgb_gt, weights, z_vals_log_s, dist_scalar, depth_scalar)
+        if hasattr(self.renderer, 'render_loss'):
+            # trainer.py:149-169 with compositing and the three losses in one kernel (and one for their backward)
+            loss, parts, rgb, weights, z_vals_log_s, aux_outputs = self.renderer.render_loss(
+                n, h, w, K, E, color_bg, rgb_gt, dist_scalar, depth_scalar, noise=self.noise)
+        else:
+            rgb, weights, z_vals_log_s, aux_outputs = self.renderer.render(n, h, w, K, E, color_bg, noise=self.noise)
+            loss, parts = helpers.fused_train_loss(rgb, rgb_gt, weights, z_vals_log_s, dist_scalar, depth_scalar)
 
         if self.logger is not None:
             loss_rgb, loss_dist, loss_depth, mse = parts[0], parts[1], parts[2], parts[3]
