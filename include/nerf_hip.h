@@ -231,6 +231,14 @@ int nerf_sample_pdf(const float* zlog, int64_t zlog_stride, const float* pdf, co
 int nerf_coarse_to_fine(const float* sigma, const float* zlog, int64_t zlog_stride, const float* noise, const float* lin,
                         int64_t n_rays, int n_samples, int n_importance, float alpha, const int32_t* steps, int n_segments,
                         float* zlog_fine, float* z_fine, void* stream);
+/* nerf_coarse_to_fine with the stratification noise of renderer.py:102 (torch.rand) drawn INSIDE the kernel: element
+ * ray * n_importance + k of the Philox4x32-10 uniform stream (seed, counter) -- 24-bit values in [0, 1), a pure function of
+ * (seed, counter, element), so a step is reproducible whatever the launch shape.  nerf_uniform_noise writes the first n
+ * elements of the same stream: nerf_coarse_to_fine on that array gives the same depths bit for bit (replay, tests). */
+int nerf_coarse_to_fine_rng(const float* sigma, const float* zlog, int64_t zlog_stride, uint64_t seed, uint64_t counter,
+                            const float* lin, int64_t n_rays, int n_samples, int n_importance, float alpha,
+                            const int32_t* steps, int n_segments, float* zlog_fine, float* z_fine, void* stream);
+int nerf_uniform_noise(uint64_t seed, uint64_t counter, int64_t n, float* out, void* stream);
 
 /* ---- alpha compositing: renderer.py:71-85 (render_rays_log) + :181-182 ---- */
 int nerf_composite_fwd(const float* sigma, const float* rgb, const float* z, const float* zlog, const float* bg /*[3]*/,

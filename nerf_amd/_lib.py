@@ -79,6 +79,9 @@ SIGNATURES = {
     'nerf_reweight': (_I, [_P, _I64, _I, _F, C.POINTER(C.c_int32), _I, _P, _P]),
     'nerf_sample_pdf': (_I, [_P, _I64, _P, _P, _P, _I64, _I, _I, _P, _P, _P, _P]),
     'nerf_coarse_to_fine': (_I, [_P, _P, _I64, _P, _P, _I64, _I, _I, _F, C.POINTER(C.c_int32), _I, _P, _P, _P]),
+    'nerf_coarse_to_fine_rng': (_I, [_P, _P, _I64, C.c_uint64, C.c_uint64, _P, _I64, _I, _I, _F, C.POINTER(C.c_int32), _I, _P, _P,
+                                     _P]),
+    'nerf_uniform_noise': (_I, [C.c_uint64, C.c_uint64, _I64, _P, _P]),
     'nerf_composite_fwd': (_I, [_P, _P, _P, _P, _P, _I64, _I, _F, _F, _P, _P, _P, _P, _P]),
     'nerf_composite_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I64, _I, _P, _P, _P]),
     'nerf_losses': (_I, [_P, _P, _P, _P, _I64, _I, _F, _F, _F, _I, _P, _P, _P, _P]),

@@ -14,6 +14,7 @@
 
 #include <stdlib.h>
 #include "common.h"
+#include "philox.h"
 
 namespace {
 
@@ -219,8 +220,9 @@ __device__ __forceinline__ void stage_reweight(const float* wpad, float* pdf, in
 }
 
 // R8 (renderer.py:87-118, :165): pdf[S] (LDS, overwritten by the cdf), zl[S] -> fine depths
+template <class NoiseFn>
 __device__ __forceinline__ void stage_sample_pdf(float* pdf_cdf, const float* zl, int S, int C, int lane,
-                                                 const float* __restrict__ noise, const float* __restrict__ lin, int Sf,
+                                                 NoiseFn noise, const float* __restrict__ lin, int Sf,
                                                  float* __restrict__ zlog_f, float* __restrict__ z_f,
                                                  int64_t* __restrict__ inds, bool live) {
     float p[kMaxC];
@@ -243,7 +245,7 @@ __device__ __forceinline__ void stage_sample_pdf(float* pdf_cdf, const float* zl
     const float c1 = cdf[1], range = cdf[S - 2] - c1, fSf = (float)Sf;
     const int n_knots = S - 3;  // cdf[1 .. S-3]
     for (int k = lane; k < Sf; k += kWave) {
-        float u = lin[k] + noise[k] / fSf;
+        float u = lin[k] + noise(k) / fSf;
         u = u * range;
         u = u + c1;
         int lo = 0, hi = n_knots;
@@ -269,7 +271,8 @@ __global__ __launch_bounds__(256) void ray_sampling_kernel(const float* __restri
                                                            int64_t zlog_stride, const float* __restrict__ noise,
                                                            const float* __restrict__ lin, int64_t n_rays, int S, int Sf,
                                                            float alpha_over_s, SegCfg seg, float* __restrict__ out_a,
-                                                           float* __restrict__ out_b, int64_t* __restrict__ inds) {
+                                                           float* __restrict__ out_b, int64_t* __restrict__ inds,
+                                                           uint64_t seed, uint64_t counter) {
     __shared__ float s_w[kRaysPerBlock][kMaxS + 2];
     __shared__ float s_p[kRaysPerBlock][kMaxS];
     __shared__ float s_z[kRaysPerBlock][kMaxS];
@@ -306,8 +309,17 @@ __global__ __launch_bounds__(256) void ray_sampling_kernel(const float* __restri
         }
     }
     // MODE 2 / 3.  Dead waves (tail block) run the stage on a clamped ray with stores masked.
-    stage_sample_pdf(pp, zl, S, C, lane, noise + ray * Sf, lin, Sf, out_a + ray * Sf, out_b ? out_b + ray * Sf : nullptr,
-                     inds ? inds + ray * Sf : nullptr, live);
+    // stratification noise (torch.rand of renderer.py:102): the caller's array, or element ray * Sf + k of the Philox stream
+    // (seed, counter) -- the same numbers nerf_uniform_noise writes out
+    if (noise) {
+        const float* nz = noise + ray * Sf;
+        stage_sample_pdf(pp, zl, S, C, lane, [&](int k) { return nz[k]; }, lin, Sf, out_a + ray * Sf,
+                         out_b ? out_b + ray * Sf : nullptr, inds ? inds + ray * Sf : nullptr, live);
+    } else {
+        const uint64_t e0 = (uint64_t)ray * (uint64_t)Sf;
+        stage_sample_pdf(pp, zl, S, C, lane, [&](int k) { return philox_uniform(seed, counter, e0 + (uint64_t)k); }, lin, Sf,
+                         out_a + ray * Sf, out_b ? out_b + ray * Sf : nullptr, inds ? inds + ray * Sf : nullptr, live);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -892,6 +904,11 @@ __global__ __launch_bounds__(256) void cum_thresh_kernel(const float* __restrict
     for (int i = lane; i < S; i += kWave) out[ray * S + i] = (i == first) ? 1.f : 0.f;
 }
 
+__global__ void uniform_noise_kernel(uint64_t seed, uint64_t counter, int64_t n, float* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) out[e] = philox_uniform(seed, counter, (uint64_t)e);
+}
+
 __global__ void zero_doubles_kernel(double* p, int n) {
     if ((int)threadIdx.x < n) p[threadIdx.x] = 0.0;
 }
@@ -960,7 +977,7 @@ int nerf_coarse_weights(const float* sigma, const float* zlog, int64_t zlog_stri
     if (n_rays <= 0) return n_rays == 0 ? 0 : NERF_EINVAL;
     SegCfg seg = {};
     ray_sampling_kernel<0><<<(unsigned)ceil_div64(n_rays, kRaysPerBlock), 256, 0, S_(stream)>>>(
-        sigma, zlog, zlog_stride, nullptr, nullptr, n_rays, n_samples, 0, 0.f, seg, weights, nullptr, nullptr);
+        sigma, zlog, zlog_stride, nullptr, nullptr, n_rays, n_samples, 0, 0.f, seg, weights, nullptr, nullptr, 0, 0);
     return nerf_launch_status("nerf_coarse_weights");
 }
 
@@ -974,7 +991,7 @@ int nerf_reweight(const float* weights, int64_t n_rays, int n_samples, float alp
     if (fill_segments(seg, steps, n_segments, n_samples, &err)) { nerf_set_error("nerf_reweight: %s", err); return NERF_EINVAL; }
     ray_sampling_kernel<1><<<(unsigned)ceil_div64(n_rays, kRaysPerBlock), 256, 0, S_(stream)>>>(
         weights, nullptr, 0, nullptr, nullptr, n_rays, n_samples, 0, (float)((double)alpha / (double)n_samples), seg, pdf,
-        nullptr, nullptr);
+        nullptr, nullptr, 0, 0);
     return nerf_launch_status("nerf_reweight");
 }
 
@@ -987,24 +1004,47 @@ int nerf_sample_pdf(const float* zlog, int64_t zlog_stride, const float* pdf, co
     if (n_rays <= 0) return n_rays == 0 ? 0 : NERF_EINVAL;
     SegCfg seg = {};
     ray_sampling_kernel<2><<<(unsigned)ceil_div64(n_rays, kRaysPerBlock), 256, 0, S_(stream)>>>(
-        pdf, zlog, zlog_stride, noise, lin, n_rays, n_samples, n_importance, 0.f, seg, zlog_fine, z_fine, inds);
+        pdf, zlog, zlog_stride, noise, lin, n_rays, n_samples, n_importance, 0.f, seg, zlog_fine, z_fine, inds, 0, 0);
     return nerf_launch_status("nerf_sample_pdf");
+}
+
+static int coarse_to_fine(const char* fn, const float* sigma, const float* zlog, int64_t zlog_stride, const float* noise,
+                          uint64_t seed, uint64_t counter, const float* lin, int64_t n_rays, int n_samples, int n_importance,
+                          float alpha, const int32_t* steps, int n_segments, float* zlog_fine, float* z_fine, void* stream) {
+    if (!(sigma && zlog && lin && steps && zlog_fine)) { nerf_set_error("%s: null pointer", fn); return NERF_EINVAL; }
+    if (n_samples < 4 || n_samples > kMaxS) { nerf_set_error("%s: n_samples must be in [4, 512]", fn); return NERF_EINVAL; }
+    if (n_importance < 1) { nerf_set_error("%s: n_importance must be positive", fn); return NERF_EINVAL; }
+    if (n_rays <= 0) return n_rays == 0 ? 0 : NERF_EINVAL;
+    SegCfg seg = {};
+    const char* err = nullptr;
+    if (fill_segments(seg, steps, n_segments, n_samples, &err)) { nerf_set_error("%s: %s", fn, err); return NERF_EINVAL; }
+    ray_sampling_kernel<3><<<(unsigned)ceil_div64(n_rays, kRaysPerBlock), 256, 0, S_(stream)>>>(
+        sigma, zlog, zlog_stride, noise, lin, n_rays, n_samples, n_importance, (float)((double)alpha / (double)n_samples), seg,
+        zlog_fine, z_fine, nullptr, seed, counter);
+    return nerf_launch_status(fn);
 }
 
 int nerf_coarse_to_fine(const float* sigma, const float* zlog, int64_t zlog_stride, const float* noise, const float* lin,
                         int64_t n_rays, int n_samples, int n_importance, float alpha, const int32_t* steps, int n_segments,
                         float* zlog_fine, float* z_fine, void* stream) {
-    NERF_REQUIRE(sigma && zlog && noise && lin && steps && zlog_fine, "null pointer");
-    NERF_REQUIRE(n_samples >= 4 && n_samples <= kMaxS, "n_samples must be in [4, 512]");
-    NERF_REQUIRE(n_importance >= 1, "n_importance must be positive");
-    if (n_rays <= 0) return n_rays == 0 ? 0 : NERF_EINVAL;
-    SegCfg seg = {};
-    const char* err = nullptr;
-    if (fill_segments(seg, steps, n_segments, n_samples, &err)) { nerf_set_error("nerf_coarse_to_fine: %s", err); return NERF_EINVAL; }
-    ray_sampling_kernel<3><<<(unsigned)ceil_div64(n_rays, kRaysPerBlock), 256, 0, S_(stream)>>>(
-        sigma, zlog, zlog_stride, noise, lin, n_rays, n_samples, n_importance, (float)((double)alpha / (double)n_samples), seg,
-        zlog_fine, z_fine, nullptr);
-    return nerf_launch_status("nerf_coarse_to_fine");
+    NERF_REQUIRE(noise, "null pointer");
+    return coarse_to_fine("nerf_coarse_to_fine", sigma, zlog, zlog_stride, noise, 0, 0, lin, n_rays, n_samples, n_importance,
+                          alpha, steps, n_segments, zlog_fine, z_fine, stream);
+}
+
+int nerf_coarse_to_fine_rng(const float* sigma, const float* zlog, int64_t zlog_stride, uint64_t seed, uint64_t counter,
+                            const float* lin, int64_t n_rays, int n_samples, int n_importance, float alpha,
+                            const int32_t* steps, int n_segments, float* zlog_fine, float* z_fine, void* stream) {
+    return coarse_to_fine("nerf_coarse_to_fine_rng", sigma, zlog, zlog_stride, nullptr, seed, counter, lin, n_rays, n_samples,
+                          n_importance, alpha, steps, n_segments, zlog_fine, z_fine, stream);
+}
+
+int nerf_uniform_noise(uint64_t seed, uint64_t counter, int64_t n, float* out, void* stream) {
+    NERF_REQUIRE(out || n == 0, "null pointer");
+    NERF_REQUIRE(n >= 0, "negative count");
+    if (n == 0) return 0;
+    uniform_noise_kernel<<<(unsigned)ceil_div64(n, 256), 256, 0, S_(stream)>>>(seed, counter, n, out);
+    return nerf_launch_status("nerf_uniform_noise");
 }
 
 int nerf_composite_fwd(const float* sigma, const float* rgb, const float* z, const float* zlog, const float* bg,

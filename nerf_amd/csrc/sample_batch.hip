@@ -10,23 +10,9 @@
 #pragma clang fp contract(off)
 
 #include "common.h"
+#include "philox.h"
 
 namespace {
-
-struct U4 { uint32_t x, y, z, w; };
-
-__host__ __device__ inline U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    return U4{c0, c1, c2, c3};
-}
-
-__device__ __forceinline__ float u01(uint32_t x) { return (float)(x & 0xFFFFFFu) * (1.0f / 16777216.0f); }   // [0, 1), 24 bits
 
 __global__ __launch_bounds__(256) void sample_batch_kernel(const uint8_t* __restrict__ images, const float* __restrict__ depths,
                                                            const float* __restrict__ K_all, const float* __restrict__ E_all,

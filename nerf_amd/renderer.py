@@ -238,15 +238,47 @@ class NerfRenderer(nn.Module):
             s_xyzs = self.mipnerf360_scale(xyzs, self.inner_bound, self.outer_bound)
             sigmas, _ = self.model.density(s_xyzs, self.outer_bound)
             sigmas = f32(sigmas)
-        if noise is None:
-            noise = torch.rand([N, n_samples], device=ro.device, generator=generator)
-        noise = f32(noise)
         zlog_f = torch.empty(N, n_samples, device=ro.device)
         z_f = torch.empty(N, n_samples, device=ro.device)
+        if noise is None:
+            # renderer.py:102's torch.rand drawn inside the kernel (Philox, a pure function of seed / call counter / element)
+            seed, counter = self._noise_stream(generator)
+            check(lib().nerf_coarse_to_fine_rng(ptr(sigmas), ptr(zlog_c), 0, seed, counter,
+                                                ptr(self._lin_table(n_samples, ro.device)), N, Sc, n_samples, alpha_const,
+                                                self._steps_array(self.steps_firstpass), len(self.steps_firstpass),
+                                                ptr(zlog_f), ptr(z_f), stream()), 'nerf_coarse_to_fine_rng')
+            return zlog_f, z_f
+        noise = f32(noise)
         check(lib().nerf_coarse_to_fine(ptr(sigmas), ptr(zlog_c), 0, ptr(noise), ptr(self._lin_table(n_samples, ro.device)),
                                         N, Sc, n_samples, alpha_const, self._steps_array(self.steps_firstpass),
                                         len(self.steps_firstpass), ptr(zlog_f), ptr(z_f), stream()), 'nerf_coarse_to_fine')
         return zlog_f, z_f
+
+    def _noise_stream(self, generator=None):
+        """(seed, counter) of the next in-kernel noise draw.  The counter is one draw from torch's HOST generator (no GPU
+        work), so the noise follows torch's seeding like the reference's torch.rand does: torch.manual_seed(s) replays the
+        same sequence of draws.  The seed is the generator's initial seed offset by the rank (data-parallel ranks draw
+        different noise).  A device generator cannot be read without a sync: its initial seed + this renderer's own call
+        count is used instead."""
+        from . import parallel
+        if generator is not None and generator.device.type != 'cpu':
+            seed = int(generator.initial_seed())
+            if getattr(self, '_noise_seed', None) != seed:
+                self._noise_seed, self._noise_counter = seed, 0
+            self._noise_counter += 1
+            counter = self._noise_counter
+        else:
+            seed = int(generator.initial_seed()) if generator is not None else int(torch.initial_seed())
+            counter = int(torch.randint(0, 2 ** 62, (1,), generator=generator))
+        seed = (seed + parallel.rank() * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        self.last_noise_stream = (seed, counter)        # render(..., noise=uniform_noise(*last_noise_stream, N, S)) replays it
+        return seed, counter
+
+    def uniform_noise(self, seed, counter, n_rays, n_samples):
+        """The [n_rays, n_samples] noise array the in-kernel draw (seed, counter) uses: render(..., noise=this) replays it."""
+        out = torch.empty(n_rays, n_samples, device='cuda')
+        check(lib().nerf_uniform_noise(seed, counter, n_rays * n_samples, ptr(out), stream()), 'nerf_uniform_noise')
+        return out
 
     def render(self, n, h, w, K, E, bg_color, noise=None, generator=None, aux=True, train_loss=None):
         """renderer.py:170-194.  ``aux=False`` (inference only, no grad): the per-sample aux outputs ``xyzs`` and
