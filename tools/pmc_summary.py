@@ -28,6 +28,9 @@ ENTRY = [
     (r'adam_kernel', 'nerf_adam_step'),
     (r'table_update_kernel', 'nerf_table_update_binned'),
     (r'bin_(count|scan|fill)(_sorted)?_kernel', 'nerf_table_bin_levels'),
+    (r'composite_loss_(fwd|finish)_kernel', 'nerf_composite_loss_fwd'),
+    (r'composite_loss_bwd_kernel', 'nerf_composite_loss_bwd'),
+    (r'sample_batch_kernel', 'nerf_sample_batch'),
     (r'composite_fwd_kernel', 'nerf_composite_fwd'),
     (r'composite_bwd_kernel', 'nerf_composite_bwd'),
     (r'losses_kernel', 'nerf_losses'),
