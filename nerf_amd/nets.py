@@ -234,9 +234,20 @@ class _FieldFn(torch.autograd.Function):
                     pipe.scatter_stream = torch.cuda.Stream()
                 done = torch.cuda.Event()
                 done.record()
-                with torch.cuda.stream(pipe.scatter_stream):
-                    pipe.scatter_stream.wait_event(done)
-                    net.scatter_levels_pipelined(src, dfeat, dtable, final=True)
+                # the small levels' LDS scatter beside the bin passes: the first group (the chunked levels) on the scatter
+                # stream, a second group (the one- and two-chunk levels, one launch) on the stream the early count pass used
+                streams = [pipe.scatter_stream]
+                if len(pipe.groups) > 1:
+                    if pipe.count_stream is None:
+                        pipe.count_stream = torch.cuda.Stream()
+                    streams.append(pipe.count_stream)
+                for gi, (l0, cnt) in enumerate(pipe.groups):
+                    st_ = streams[min(gi, len(streams) - 1)]
+                    with torch.cuda.stream(st_):
+                        st_.wait_event(done)
+                        check(lib().nerf_hashgrid_scatter(C.byref(net.encoder.cfg), C.byref(src), ptr(dfeat), ptr(dtable), l0, cnt,
+                                                          stream()), 'nerf_hashgrid_scatter')
+                        pipe.level_done(l0, cnt)
             pipe.bin(net.encoder.cfg, src, dfeat, dfeat.shape[1], net.encoder.level_cols, dtable, keepalive=ctx.src_kwargs,
                      tag=ctx.count_tag)
         elif pipe is None or not direct or cut * unit < 65536 or (rows - cut) * unit < 65536:

@@ -12,6 +12,7 @@ from ._lib import NerfLevelSet, check, lib, ptr, stream
 
 
 SMALL_TENSORS_ON_SIDE_STREAM = os.environ.get('NERF_SMALL_ADAM_SIDE', '1') != '0'
+SPLIT_SMALL_GROUP = os.environ.get('NERF_SPLIT_SMALL', '1') != '0'
 
 
 class TablePipeline(object):
@@ -52,8 +53,16 @@ class TablePipeline(object):
             # levels are groups of their own
             small = [l for l in dense if grid_cfg.entries[l] * n_features <= 16 * 32768]
             big = [(l, 1) for l in reversed(dense) if l not in small]
-            small = [(small[0], len(small))] if small and small == list(range(small[0], small[0] + len(small))) else \
-                    [(l, 1) for l in small]
+            if small and small == list(range(small[0], small[0] + len(small))):
+                # one group -- or two, when the binned update is on: the chunked levels (three LDS chunks and more) and the
+                # one- or two-chunk levels then scatter on two streams side by side (see _FieldFn.backward)
+                few = [l for l in small if grid_cfg.entries[l] * n_features <= 2 * 32768]
+                if self.binned_levels and few and len(few) < len(small) and few == small[:len(few)] and SPLIT_SMALL_GROUP:
+                    small = [(small[len(few)], len(small) - len(few)), (few[0], len(few))]
+                else:
+                    small = [(small[0], len(small))]
+            else:
+                small = [(l, 1) for l in small]
             # hashed levels first (most Adam work released per scatter), small levels last: measured best of the
             # four obvious orders
             groups = hashed + big + small
@@ -246,6 +255,8 @@ class FusedAdam(torch.optim.Optimizer):
             pipe.drop_binned()
             if pipe.scatter_stream is not None:     # scatters of the discarded pass may still be running beside us
                 torch.cuda.current_stream().wait_stream(pipe.scatter_stream)
+            if pipe.count_stream is not None:
+                torch.cuda.current_stream().wait_stream(pipe.count_stream)
             for w in pipe.works.values():
                 if w is not None:
                     w.wait()
