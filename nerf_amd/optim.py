@@ -294,8 +294,7 @@ class FusedAdam(torch.optim.Optimizer):
         # One GPU with the binned table update: the small tensors (MLPs, latent table) take their Adam step on the side
         # stream BESIDE the table passes instead of after them (three 7 us launches at the very end of the step otherwise)
         pipe = self._pipeline
-        early = (pipe is not None and bool(pipe.binned_levels) and pipe.pending and self._sharding is None
-                 and SMALL_TENSORS_ON_SIDE_STREAM)
+        early = pipe is not None and pipe.pending and SMALL_TENSORS_ON_SIDE_STREAM
         if early:
             if pipe.side is None:
                 pipe.side = torch.cuda.Stream()

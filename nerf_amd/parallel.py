@@ -77,12 +77,31 @@ def all_reduce_sum_(t, async_op=False):
     return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op)
 
 
+class _PackedReduce(object):
+    """Handle of an asynchronous packed all-reduce: wait() makes the CURRENT stream wait for the collective and then
+    unpacks the flat buffer into the gradients / flags it was packed from."""
+
+    def __init__(self, work, flat, small, flags):
+        self.work, self.flat, self.small, self.flags = work, flat, small, flags
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+        o = 0
+        for p in self.small:
+            p.grad.copy_(self.flat[o:o + p.numel()].view_as(p.grad))
+            o += p.numel()
+        for f in self.flags:
+            f.copy_(self.flat[o:o + f.numel()].view_as(f))
+            o += f.numel()
+
+
 def all_reduce_grads(params, async_op=False, skip=(), flags=()):
     """SUM-all-reduce the .grad of every parameter (largest first so the big transfer starts early).
     `skip`: parameters whose gradient is reduced elsewhere (the pipelined hash table).
     `flags`: small counters (the non-finite flag of the loss) that ride in the same collective as the small
     gradients -- a collective of their own would cost one more latency per step; values must be exact in fp32.
-    Returns the list of work handles when async_op."""
+    Returns the list of handles to wait() on when async_op (wait() makes the current stream wait and unpacks)."""
     if not dist.is_initialized():
         return []
     handles = []
@@ -91,17 +110,14 @@ def all_reduce_grads(params, async_op=False, skip=(), flags=()):
                   key=lambda t: -t.numel())
     small = [p for p in todo if p.numel() <= (1 << 20)]
     flags = [f for f in flags if f is not None]
-    if len(small) + len(flags) > 1 and not async_op:
+    if len(small) + len(flags) > 1:
         # the MLP / latent gradients are a few KB each: one collective for all of them
         flat = torch.cat([p.grad.reshape(-1) for p in small] + [f.reshape(-1).to(torch.float32) for f in flags])
-        all_reduce_sum_(flat)
-        o = 0
-        for p in small:
-            p.grad.copy_(flat[o:o + p.numel()].view_as(p.grad))
-            o += p.numel()
-        for f in flags:
-            f.copy_(flat[o:o + f.numel()].view_as(f))
-            o += f.numel()
+        h = _PackedReduce(all_reduce_sum_(flat, async_op=async_op), flat, small, flags)
+        if async_op:
+            handles.append(h)
+        else:
+            h.wait()
         todo = [p for p in todo if p.numel() > (1 << 20)]
         flags = []
     for f in flags:
