@@ -100,8 +100,9 @@ class Trainer(object):
     def load_checkpoint(self, path, map_location='cuda'):
         """Resume from a file written by save_checkpoint.  NOT a loader for .pth files trained by the reference: the keys
         match (encoder.params, sigma_net.params, color_net.params, latent_emb) but tinycudann's FullyFusedMLP stores its
-        layers padded to multiples of 16 inputs / outputs, so load_state_dict reports a size mismatch for them; the
-        padded layout is unpinned (tinycudann is absent, the reference ships no checkpoint) and is not converted."""
+        layers padded to multiples of 16 inputs / outputs, so load_state_dict reports a size mismatch for them.
+        nerf_amd.tcnn_compat.from_reference_state_dict converts tiny-cuda-nn's published layout (UNPINNED: tinycudann is
+        absent here and the reference ships no checkpoint to check it against); nothing is converted silently."""
         ck = torch.load(path, map_location=map_location, weights_only=True)
         self.model.load_state_dict(ck['model'])
         self.optimizer.load_state_dict(ck['optimizer'])
