@@ -33,7 +33,33 @@ from ._lib import NerfColMap, NerfLevelSet, check, lib, ptr, stream
 def _binned_hashed():
     """Whether the hashed levels take the binned update under level sharding (optim.FusedAdam.attach reads the same
     switch; it must be set alike on every rank)."""
-    return os.environ.get('NERF_TABLE_BINNED_SHARDED', 'hashed') != '0'
+    return os.environ.get('NERF_TABLE_BINNED_SHARDED', 'auto') != '0'
+
+
+def sharded_binned_levels(cfg, world, mode=None):
+    """The levels whose OWNER applies the binned table update (csrc/table_update.hip) in a world of `world` ranks.
+    mode (NERF_TABLE_BINNED_SHARDED): '0' none; '1' every level of more than 512 K floats; 'hashed' the hashed ones of
+    those; 'auto' (default) the hashed ones plus the dense ones whose partitions stay light: an owner sees the points of ALL
+    ranks, the clustered points of a dense level pile into its few partitions, and one workgroup only sums ~0.3 G items/s
+    (a rank owning levels 3, 4, 5 at world 8: 4.7 -> 9.2 ms with everything binned), so a dense level is binned while
+    8 corners x world x 524 288 points / partitions stays under 110 K items per partition (measured with
+    tools/shard_step_emulate.py: at world 2 binning level 5 of config_base -- 64 partitions, 131 K items each -- costs
+    0.1 ms, at world 4 binning level 6 -- 163 partitions, 103 K items each -- gains 0.06 ms; levels 8-11 are binned at
+    every world)."""
+    mode = os.environ.get('NERF_TABLE_BINNED_SHARDED', 'auto') if mode is None else mode
+    out = []
+    F = cfg.n_features
+    for l in range(cfg.n_levels):
+        floats = int(cfg.entries[l]) * F
+        if mode == '0' or not (16 * 32768 < floats <= 8192 * 16384):
+            continue
+        if mode == '1' or cfg.hashed[l]:
+            out.append(l)
+        elif mode == 'auto':
+            parts = (floats + 16383) // 16384
+            if 8 * world * 524288 / parts <= float(os.environ.get('NERF_SHARD_BIN_ITEMS', '110000')):
+                out.append(l)
+    return out
 
 
 def level_costs(cfg, world=8, binned_hashed=None):
@@ -55,6 +81,7 @@ def level_costs(cfg, world=8, binned_hashed=None):
     """
     if binned_hashed is None:
         binned_hashed = _binned_hashed()
+    binned_set = set(sharded_binned_levels(cfg, world)) if binned_hashed else set()
     out = []
     hashed = [l for l in range(cfg.n_levels) if cfg.hashed[l]]
     for l in range(cfg.n_levels):
@@ -66,9 +93,11 @@ def level_costs(cfg, world=8, binned_hashed=None):
             scatter = 0.03 if floats <= 2 * 32768 else (0.03 + 0.03 * floats / (16 * 32768.0) if floats <= 16 * 32768 else 0.09)
             encode = 0.005 + 0.007 * min(1.0, cfg.entries[l] / float(1 << 24))
         adam = floats * 32 / 5.4e9
-        if cfg.hashed[l] and binned_hashed and floats > 16 * 32768:
+        if cfg.hashed[l] and l in binned_set:
             scatter, adam = 0.055, floats * 24 / 5.0e9
             encode = 0.015 + 0.010 * (l - hashed[0]) / max(1, len(hashed) - 1)
+        elif l in binned_set:       # a dense level under the binned update: bin passes instead of memory-side atomics
+            scatter, adam = 0.055, floats * 24 / 5.0e9
         out.append(world * (scatter + 1.5 * encode) + adam + 0.05)     # + launches and exchange bookkeeping per level
     return out
 

@@ -37,8 +37,11 @@ class TablePipeline(object):
         if binned:
             own = list(range(L)) if levels is None else sorted(levels)
             # (upper bound: nerf_table_bin_levels takes at most 8192 partitions of 16 K floats per level)
-            self.binned_levels = [l for l in own if 16 * 32768 < int(grid_cfg.entries[l]) * n_features <= 8192 * 16384
-                                  and (binned != 'hashed' or grid_cfg.hashed[l])]
+            if isinstance(binned, (list, tuple, set)):      # an explicit choice (level sharding: level_parallel.sharded_binned_levels)
+                self.binned_levels = [l for l in own if l in binned]
+            else:
+                self.binned_levels = [l for l in own if 16 * 32768 < int(grid_cfg.entries[l]) * n_features <= 8192 * 16384
+                                      and (binned != 'hashed' or grid_cfg.hashed[l])]
             rest = [l for l in own if l not in self.binned_levels]
             if levels is not None:
                 levels = rest
@@ -233,10 +236,10 @@ class FusedAdam(torch.optim.Optimizer):
             # into a handful of partitions and the binned update gets slower than the atomic scatter, measured with
             # tools/shard_step_emulate.py -- so only the hashed levels, whose partitions fill evenly, are binned here;
             # NERF_TABLE_BINNED_SHARDED=0 / 1 turns it off / on for every large level)
-            mode = os.environ.get('NERF_TABLE_BINNED_SHARDED', 'hashed')
+            from .level_parallel import sharded_binned_levels
+            chosen = sharded_binned_levels(model.encoder.cfg, sh.world)
             model.table_pipeline = TablePipeline(model.encoder.cfg, model.encoder.cfg.n_features, levels=sh.mine,
-                                                 reduce=False,
-                                                 binned={'0': False, '1': True}.get(mode, 'hashed'))
+                                                 reduce=False, binned=chosen if chosen else False)
             self._pipeline = model.table_pipeline
         elif pipeline:
             model.table_pipeline = TablePipeline(model.encoder.cfg, model.encoder.cfg.n_features)
