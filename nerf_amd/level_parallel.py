@@ -234,10 +234,10 @@ class LevelSharding(object):
             return [float(f) for f in env.split(',')] if ',' in env else max(1, int(env))
         if self.world <= 1 or n_points < 131072:
             return 1
-        # measured with the modelled wire (tools/shard_step_emulate.py, profiles/r02c_shard_wire_*.log): two groups win
-        # at worlds 2 and 4 (5.78 -> 5.59 and 4.98 -> 4.81 ms), at world 8 the per-link volume is too small to matter,
-        # and four groups lose more to the smaller launches than they hide
-        return 2 if self.world <= 4 else 1
+        # measured with the modelled wire (tools/shard_step_emulate.py): two groups win at every world once the scatters
+        # run beside the exchange on their own stream (4.75 vs 5.33 / 4.32 vs 4.63 / 4.33 vs 4.45 ms at 2 / 4 / 8 ranks,
+        # profiles/r02h_shard_*.log); four groups lose more to the smaller launches than they hide
+        return 2
 
     def plan(self, kw, groups=None):
         """Gather the point source of every rank (one all-gather, as gather_src) and cut it into ray groups.
@@ -447,33 +447,41 @@ class LevelSharding(object):
         early = [l for l in self.mine if l not in binned]
         if wm and early:
             own = self._sub_src(src_all, r, r + 1, M)
-            if len(early) == len(self.mine):
-                self._scatter(own, self.my_set, ptr(send_blocks[r]), wm, dtable)
-            else:
-                for l in early:
-                    self._scatter(own, _level_set([l]), ptr(send_blocks[r]) + 4 * slot[l] * self.F, wm, dtable)
+            with self._scatter_side(pipe):      # (the scatter stream with a pipeline: beside the exchange AND what follows)
+                if len(early) == len(self.mine):
+                    self._scatter(own, self.my_set, ptr(send_blocks[r]), wm, dtable)
+                else:
+                    for l in early:
+                        self._scatter(own, _level_set([l]), ptr(send_blocks[r]) + 4 * slot[l] * self.F, wm, dtable)
         if wm and binned:
             recv_blocks[r].copy_(send_blocks[r])        # recv becomes the whole [W*M, wm] gradient matrix, rank-major
-        if work is not None:
-            work.wait()
         if not wm:
+            if work is not None:
+                work.wait()
             return
         remote = [(a, b) for (a, b) in ((0, r), (r + 1, W)) if b > a]
         if pipe is None:
+            if work is not None:
+                work.wait()
             for (a, b) in remote:
                 self._scatter(self._sub_src(src_all, a, b, M), self.my_set, ptr(recv_blocks[a]), wm, dtable)
             return
-        for (l0, cnt) in pipe.groups:
-            for l in range(l0, l0 + cnt):
-                one = _level_set([l])
-                for (a, b) in remote:
-                    self._scatter(self._sub_src(src_all, a, b, M), one, ptr(recv_blocks[a]) + 4 * slot[l] * self.F, wm, dtable)
-            pipe.level_done(l0, cnt)
+        pipe.keep += [send, recv, src_all]
+        with self._scatter_side(pipe):
+            if work is not None:
+                work.wait()         # the scatter stream waits for the exchange ...
+            for (l0, cnt) in pipe.groups:
+                for l in range(l0, l0 + cnt):
+                    one = _level_set([l])
+                    for (a, b) in remote:
+                        self._scatter(self._sub_src(src_all, a, b, M), one, ptr(recv_blocks[a]) + 4 * slot[l] * self.F, wm, dtable)
+                pipe.level_done(l0, cnt)
+        if work is not None:
+            work.wait()             # ... and so does the main stream, for the bin pass below
         if binned:
             # binned update of the large levels: the corner updates of the points of ALL ranks are sorted into table
             # partitions here; FusedAdam.step sums and applies them in one pass (no gradient array, no atomics)
             from .nets import make_point_src
-            pipe.keep += [recv, src_all]
             pipe.bin(self.cfg, make_point_src(**self._sub_src(src_all, 0, W, M)), recv, wm,
                      {l: slot[l] * self.F for l in binned}, dtable, keepalive=src_all)
 
@@ -501,9 +509,25 @@ class LevelSharding(object):
         state['keep'].append(send)
         if wm and dtable is not None:
             binned = list(pipe.binned_levels) if pipe is not None else []
-            self._scatter_rows(grp['kw_all'], r, r + 1, m, ptr(send_blocks[r]), binned, dtable)
-            self._scatter_arrived(state, len(state['works']) - 1, binned, dtable)
+            with self._scatter_side(pipe):
+                self._scatter_rows(grp['kw_all'], r, r + 1, m, ptr(send_blocks[r]), binned, dtable)
+                self._scatter_arrived(state, len(state['works']) - 1, binned, dtable)
         return state
+
+    def _scatter_side(self, pipe):
+        """Context for the atomic / LDS scatter of the levels that are not binned: with a TablePipeline they run on its
+        scatter stream, BESIDE the backward kernel of the next group, the bin passes and the update pass (one rank at world 2
+        spent 0.6 ms of a 5 ms step in eight such launches on the main stream); the stream first waits for what the main
+        stream has produced so far (the rows just split off d(features))."""
+        if pipe is None or not torch.cuda.is_available():
+            import contextlib
+            return contextlib.nullcontext()
+        if pipe.scatter_stream is None:
+            pipe.scatter_stream = torch.cuda.Stream()
+        ready = torch.cuda.Event()
+        ready.record()
+        pipe.scatter_stream.wait_event(ready)
+        return torch.cuda.stream(pipe.scatter_stream)
 
     def _scatter_rows(self, src_all, qa, qb, m, base_ptr, binned, dtable):
         """Atomic scatter of the non-binned levels of mine for the points of ranks [qa, qb) of one group; `base_ptr`:
@@ -537,16 +561,16 @@ class LevelSharding(object):
         wm = self.width[self.rank]
         binned = list(pipe.binned_levels) if pipe is not None else []
         if wm:
-            self._scatter_arrived(state, len(state['works']), binned, dtable)
-        else:
-            for work, _g, _b in state['works']:
-                if work is not None:
-                    work.wait()
+            with self._scatter_side(pipe):
+                self._scatter_arrived(state, len(state['works']), binned, dtable)
+                if pipe is not None:
+                    for (l0, cnt) in pipe.groups:       # events on the scatter stream: the Adam slices wait for them
+                        pipe.level_done(l0, cnt)
+        for work, _g, _b in state['works']:     # the main stream needs every group's rows too (bin pass below)
+            if work is not None:
+                work.wait()
+        if not wm or pipe is None:
             return
-        if pipe is None:
-            return
-        for (l0, cnt) in pipe.groups:
-            pipe.level_done(l0, cnt)
         recv, src_all = state['recv'], plan['kw_all']
         pipe.keep += [recv, src_all, state['keep']]
         if binned:
