@@ -315,6 +315,13 @@ int nerf_table_bin_count(const NerfGridCfg* grid, const NerfPointSrc* src, const
 int nerf_table_bin_fill(const NerfGridCfg* grid, const NerfPointSrc* src, const NerfLevelSet* levels, const float* dfeat,
                         int64_t dfeat_stride, const int32_t* dfeat_cols, void* workspace, int64_t workspace_bytes,
                         void* stream);
+/* The fill for the points [p_begin, p_end) of `src` only (whole chunks of 16 384 points; p_end may also be n_points):
+ * under level sharding the rows of d(features) reach a level's owner ray group by ray group, and the rows of a group are
+ * sorted into the partitions while the next group is still on the wire.  Every point must be filled exactly once before
+ * nerf_table_update_binned; dfeat is the base of the full matrix (row = point index in `src`). */
+int nerf_table_bin_fill_range(const NerfGridCfg* grid, const NerfPointSrc* src, const NerfLevelSet* levels, const float* dfeat,
+                              int64_t dfeat_stride, const int32_t* dfeat_cols, void* workspace, int64_t workspace_bytes,
+                              int64_t p_begin, int64_t p_end, void* stream);
 /* table / exp_avg / exp_avg_sq: the WHOLE table's tensors (level offsets come from grid); only the listed levels change.
  * n_points and levels must be those of the nerf_table_bin_levels call that filled the workspace. */
 int nerf_table_update_binned(const NerfGridCfg* grid, const NerfLevelSet* levels, int64_t n_points, const void* workspace,

@@ -94,6 +94,7 @@ SIGNATURES = {
     'nerf_table_bin_levels': (_I, [_G, _S, _LS, _P, _I64, C.POINTER(C.c_int32), _P, _I64, _P]),
     'nerf_table_bin_count': (_I, [_G, _S, _LS, _P, _I64, _P]),
     'nerf_table_bin_fill': (_I, [_G, _S, _LS, _P, _I64, C.POINTER(C.c_int32), _P, _I64, _P]),
+    'nerf_table_bin_fill_range': (_I, [_G, _S, _LS, _P, _I64, C.POINTER(C.c_int32), _P, _I64, _I64, _I64, _P]),
     'nerf_table_update_binned': (_I, [_G, _LS, _I64, _P, _I64, _P, _P, _P, _F, _F, _F, _F, _F, _I64, _F, _P]),
     'nerf_cum_weights_thresh': (_I, [_P, _I64, _I, _F, _P, _P]),
 }

@@ -156,21 +156,22 @@ __global__ __launch_bounds__(kBinThreads) void bin_scan_kernel(BinPlan plan, int
 
 // pass 3: write every item (partition-local float offset, F gradient values) to its place in its bin
 template <int F>
-__global__ __launch_bounds__(kBinThreads) void bin_fill_kernel(GridDev g, NerfPointSrc src, BinPlan plan, int64_t M, int nwg,
+__global__ __launch_bounds__(kBinThreads) void bin_fill_kernel(GridDev g, NerfPointSrc src, BinPlan plan, int64_t M, int chunk0,
                                                                const uint32_t* __restrict__ offs,
                                                                const float* __restrict__ dfeat, int64_t stride,
                                                                uint16_t* __restrict__ item_idx, float* __restrict__ item_val) {
     __shared__ uint32_t cur[kMaxBinsPerLevel];
     const int slot = blockIdx.y, l = plan.level[slot];
     const uint32_t nb = plan.nbins[slot];
-    const uint32_t* o = offs + plan.hist_off[slot] + (int64_t)blockIdx.x * nb;
+    const int64_t chunk = (int64_t)blockIdx.x + chunk0;         // (a launch may cover a range of the chunks only)
+    const uint32_t* o = offs + plan.hist_off[slot] + chunk * nb;
     for (uint32_t i = threadIdx.x; i < nb; i += kBinThreads) cur[i] = o[i];
     __syncthreads();
     const LevelP lp = plan_level(g, l);
     const int col = plan.col[slot];
     uint16_t* ii = item_idx + plan.item_off[slot];
     float* iv = item_val + plan.item_off[slot] * F;
-    const int64_t p0 = (int64_t)blockIdx.x * kBinChunkPts;
+    const int64_t p0 = chunk * kBinChunkPts;
     const int64_t p1 = p0 + kBinChunkPts < M ? p0 + kBinChunkPts : M;
     for (int64_t p = p0 + threadIdx.x; p < p1; p += kBinThreads) {
         const PointIn q = fetch_point(src, p, false);
@@ -217,7 +218,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
 
 template <int F>
 __global__ __launch_bounds__(kBinThreads) void bin_fill_sorted_kernel(GridDev g, NerfPointSrc src, BinPlan plan, int64_t M,
-                                                                      int nwg, uint32_t nb_max,
+                                                                      int chunk0, uint32_t nb_max,
                                                                       const uint32_t* __restrict__ offs,
                                                                       const float* __restrict__ dfeat, int64_t stride,
                                                                       uint16_t* __restrict__ item_idx,
@@ -236,7 +237,8 @@ __global__ __launch_bounds__(kBinThreads) void bin_fill_sorted_kernel(GridDev g,
     const int slot = blockIdx.y, l = plan.level[slot];
     const uint32_t nb = plan.nbins[slot];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    const uint32_t* o = offs + plan.hist_off[slot] + (int64_t)blockIdx.x * nb;
+    const int64_t chunk = (int64_t)blockIdx.x + chunk0;         // (a launch may cover a range of the chunks only)
+    const uint32_t* o = offs + plan.hist_off[slot] + chunk * nb;
     for (uint32_t i = threadIdx.x; i < nb; i += kBinThreads) { cur[i] = o[i]; cnt[i] = 0u; }
     __syncthreads();
     // From here on the barriers order LDS traffic only (s_waitcnt lgkmcnt(0) + s_barrier): nothing in global memory is
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_fill_sorted_kernel(GridDev g,
     const int col = plan.col[slot];
     uint16_t* ii = item_idx + plan.item_off[slot];
     float* iv = item_val + plan.item_off[slot] * F;
-    const int64_t p0 = (int64_t)blockIdx.x * kBinChunkPts;
+    const int64_t p0 = chunk * kBinChunkPts;
     const int64_t p1 = p0 + kBinChunkPts < M ? p0 + kBinChunkPts : M;
     const uint32_t per = (nb + kBinThreads - 1) / kBinThreads;     // consecutive bins per thread in the scan
     // this thread's point of the coming round: position and gradient are requested one round ahead
@@ -523,7 +525,7 @@ namespace {
 // count + scan (which need only the points) and / or the fill (which needs the gradient rows) of nerf_table_bin_levels
 int bin_passes(const char* fn, const NerfGridCfg* grid, const NerfPointSrc* src, const NerfLevelSet* levels, const float* dfeat,
                int64_t dfeat_stride, const int32_t* dfeat_cols, void* workspace, int64_t workspace_bytes, void* stream,
-               bool do_count, bool do_fill) {
+               bool do_count, bool do_fill, int64_t p_begin = 0, int64_t p_end = -1) {
     if (!grid || !workspace || (do_fill && !dfeat)) { nerf_set_error("%s: null pointer", fn); return NERF_EINVAL; }
     int rc = nerf_check_src(fn, src, false);
     if (rc) return rc;
@@ -548,6 +550,14 @@ int bin_passes(const char* fn, const NerfGridCfg* grid, const NerfPointSrc* src,
     hipStream_t st = (hipStream_t)stream;
     const dim3 nb((unsigned)lay.nwg, (unsigned)plan.count);
     const int64_t M = src->n_points;
+    // the fill may cover a range of the points only (whole chunks): the rows of d(features) arrive group by group
+    if (p_end < 0) p_end = M;
+    if (p_begin < 0 || p_begin > p_end || p_end > M || p_begin % kBinChunkPts || (p_end % kBinChunkPts && p_end != M)) {
+        nerf_set_error("%s: point range must be whole chunks of %d points", fn, kBinChunkPts); return NERF_EINVAL;
+    }
+    const int chunk0 = (int)(p_begin / kBinChunkPts);
+    const dim3 nbf((unsigned)(ceil_div64(p_end, kBinChunkPts) - chunk0), (unsigned)plan.count);
+    if (do_fill && nbf.x == 0) return 0;
     uint32_t nb_max = 0;
     for (int i = 0; i < plan.count; ++i) nb_max = plan.nbins[i] > nb_max ? plan.nbins[i] : nb_max;
     nb_max = (nb_max + 3u) & ~3u;            // keeps the staged arrays behind the counters 16-byte aligned
@@ -564,11 +574,11 @@ int bin_passes(const char* fn, const NerfGridCfg* grid, const NerfPointSrc* src,
             auto kern = bin_fill_sorted_kernel<FF>;                                                                    \
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, sorted_lds); \
             if (e != hipSuccess) { nerf_set_error("%s: LDS attribute: %s", fn, hipGetErrorString(e)); return (int)e; }  \
-            kern<<<nb, kBinThreads, sorted_lds, st>>>(g, *src, plan, M, lay.nwg, nb_max, hist, dfeat, dfeat_stride, item_idx, \
-                                                      item_val);                                                       \
+            kern<<<nbf, kBinThreads, sorted_lds, st>>>(g, *src, plan, M, chunk0, nb_max, hist, dfeat, dfeat_stride, item_idx, \
+                                                       item_val);                                                      \
         } else if (do_fill) {                                                                                          \
-            bin_fill_kernel<FF><<<nb, kBinThreads, 0, st>>>(g, *src, plan, M, lay.nwg, hist, dfeat, dfeat_stride, item_idx, \
-                                                            item_val);                                                 \
+            bin_fill_kernel<FF><<<nbf, kBinThreads, 0, st>>>(g, *src, plan, M, chunk0, hist, dfeat, dfeat_stride, item_idx, \
+                                                             item_val);                                                \
         }                                                                                                              \
     } while (0)
     switch (F) {
@@ -600,6 +610,13 @@ extern "C" int nerf_table_bin_fill(const NerfGridCfg* grid, const NerfPointSrc* 
                                    int64_t workspace_bytes, void* stream) {
     return bin_passes("nerf_table_bin_fill", grid, src, levels, dfeat, dfeat_stride, dfeat_cols, workspace, workspace_bytes,
                       stream, false, true);
+}
+
+extern "C" int nerf_table_bin_fill_range(const NerfGridCfg* grid, const NerfPointSrc* src, const NerfLevelSet* levels,
+                                         const float* dfeat, int64_t dfeat_stride, const int32_t* dfeat_cols, void* workspace,
+                                         int64_t workspace_bytes, int64_t p_begin, int64_t p_end, void* stream) {
+    return bin_passes("nerf_table_bin_fill_range", grid, src, levels, dfeat, dfeat_stride, dfeat_cols, workspace,
+                      workspace_bytes, stream, false, true, p_begin, p_end);
 }
 
 extern "C" int nerf_table_update_binned_guarded(const NerfGridCfg* grid, const NerfLevelSet* levels, int64_t n_points,

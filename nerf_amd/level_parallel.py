@@ -30,6 +30,9 @@ from . import parallel
 from ._lib import NerfColMap, NerfLevelSet, check, lib, ptr, stream
 
 
+RANGED_FILL = os.environ.get('NERF_SHARD_RANGED_FILL', '1') != '0'
+
+
 def _binned_hashed():
     """Whether the hashed levels take the binned update under level sharding (optim.FusedAdam.attach reads the same
     switch; it must be set alike on every rank)."""
@@ -295,7 +298,7 @@ class LevelSharding(object):
                    n_points=W * kw['n_points'])
         return out
 
-    def encode_exchange_groups(self, table, plan, xh):
+    def encode_exchange_groups(self, table, plan, xh, after_last_start=None):
         """Generator over the plan's groups, in order: yields a group once rows [a, b) of `xh` hold its feature rows.
         Schedule on the compute stream: E0 | E1 F0 | E2 F1 | ... | F(G-1), where E = encode my levels for the
         group (remote points, start the all-to-all, own points) and F = wait + shuffle into xh; the caller's MLP on
@@ -303,6 +306,8 @@ class LevelSharding(object):
         pend = None
         for grp in plan['groups']:
             st = self._encode_start(table, grp['kw_all'], grp['m'])
+            if after_last_start is not None and grp is plan['groups'][-1]:
+                after_last_start()      # every exchange of this pass is on its way: side work from here delays no wire
             if pend is not None:
                 self._encode_finish(pend[0], pend[1], xh)
                 yield pend[1]
@@ -495,10 +500,19 @@ class LevelSharding(object):
         M, m = plan['m_local'], grp['m']
         if state is None:
             state = {'recv': torch.empty(W * M * wm, device=dfeat_rows.device, dtype=torch.float32), 'works': [], 'keep': [],
-                     'scattered': 0, 'begun': False}
+                     'scattered': 0, 'begun': False, 'ranged': False, 'filled': 0}
         if pipe is not None and dtable is not None and not state['begun']:
             pipe.begin(dtable)
             state['begun'] = True
+            # binned levels: the rows of a group are sorted into the partitions while the NEXT group is on the wire (the
+            # count + scan passes ran under the forward pass, see _ShardedFieldFn.forward); needs groups of whole chunks
+            chunk = 16384
+            if wm and pipe.binned_levels and all((W * g['a']) % chunk == 0 for g in plan['groups']) and RANGED_FILL:
+                from .nets import make_point_src
+                slot = {l: i for i, l in enumerate(self.mine)}
+                state['ranged'] = pipe.bin_ranges_start(self.cfg, make_point_src(**plan['kw_all']), state['recv'], wm,
+                                                        {l: slot[l] * self.F for l in pipe.binned_levels}, dtable,
+                                                        keepalive=plan['kw_all'], tag=plan.get('count_tag'))
         send = self.split(dfeat_rows)
         recv_g = state['recv'][W * grp['a'] * wm:W * grp['b'] * wm]
         send_blocks, recv_blocks = self._blocks(send, m, self.width), self._blocks(recv_g, m, [wm] * W)
@@ -512,7 +526,20 @@ class LevelSharding(object):
             with self._scatter_side(pipe):
                 self._scatter_rows(grp['kw_all'], r, r + 1, m, ptr(send_blocks[r]), binned, dtable)
                 self._scatter_arrived(state, len(state['works']) - 1, binned, dtable)
+            self._fill_arrived(state, len(state['works']) - 1, pipe)
         return state
+
+    def _fill_arrived(self, state, upto, pipe):
+        """Ranged fill (main stream) of the groups [state['filled'], upto): their exchanges are waited for first."""
+        if not state['ranged']:
+            return
+        W = self.world
+        while state['filled'] < upto:
+            work, grp, _blocks = state['works'][state['filled']]
+            if work is not None:
+                work.wait()
+            pipe.bin_range(W * grp['a'], W * grp['b'])
+            state['filled'] += 1
 
     def _scatter_side(self, pipe):
         """Context for the atomic / LDS scatter of the levels that are not binned: with a TablePipeline they run on its
@@ -570,6 +597,11 @@ class LevelSharding(object):
             if work is not None:
                 work.wait()
         if not wm or pipe is None:
+            return
+        if state['ranged']:
+            self._fill_arrived(state, len(state['works']), pipe)
+            pipe.keep += [state['recv'], plan['kw_all'], state['keep']]
+            pipe.bin_ranges_finish()
             return
         recv, src_all = state['recv'], plan['kw_all']
         pipe.keep += [recv, src_all, state['keep']]

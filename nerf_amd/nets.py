@@ -161,6 +161,8 @@ def _slice_src_kwargs(kw, a, b, unit):
 
 
 EARLY_BIN_COUNT = os.environ.get('NERF_EARLY_BIN_COUNT', '1') != '0'
+SHARD_COUNT_STREAM = os.environ.get('NERF_SHARD_COUNT_STREAM', 'scatter')
+SHARD_COUNT_AT = os.environ.get('NERF_SHARD_COUNT_AT', 'last')      # level sharding: 'first' = before the first encode
 
 
 class _FieldFn(torch.autograd.Function):
@@ -325,12 +327,29 @@ class _ShardedFieldFn(torch.autograd.Function):
         M = src.n_points
         dev = table.device
         plan = sh.plan(src_kwargs)
+        pipe = net.table_pipeline
+        count_now = None
+        if (pipe is not None and net.direct_grads and pipe.binned_levels and ctx.needs_input_grad[0] and EARLY_BIN_COUNT
+                and sh.width[sh.rank]):
+            # count + scan passes of the owner's binned levels over the points of ALL ranks: under this forward pass, once the
+            # last group's features are on the wire (before that they would delay an exchange by sharing the CUs with an encode)
+            def count_now():
+                plan['count_tag'] = net.forward_count = getattr(net, 'forward_count', 0) + 1
+                # (on the scatter stream, idle in a forward pass: with the collectives' stream a stream of its own would be the
+                # fifth of this process, and the hardware has four queues: it would share one with the exchange it runs beside)
+                if pipe.scatter_stream is None:
+                    pipe.scatter_stream = torch.cuda.Stream()
+                pipe.count_early(net.encoder.cfg, make_point_src(**plan['kw_all']), plan['count_tag'], dev,
+                                 on=pipe.scatter_stream if SHARD_COUNT_STREAM == 'scatter' else None)
+            if SHARD_COUNT_AT == 'first':
+                count_now()
+                count_now = None
         sigma = torch.empty(M, device=dev, dtype=torch.float32)
         rgb = torch.empty(M, 3, device=dev, dtype=torch.float32)
         xyz = torch.empty(M, 3, device=dev, dtype=torch.float32) if want_xyz else None
         xh = torch.empty(M, net.encoder.n_output_dims, device=dev, dtype=torch.float32)
         # group by group: the MLPs of a group run while the next group's features are on the wire
-        for grp in sh.encode_exchange_groups(table, plan, xh):
+        for grp in sh.encode_exchange_groups(table, plan, xh, after_last_start=count_now):
             a, b = grp['a'], grp['b']
             sub = src if len(plan['groups']) == 1 else make_point_src(**grp['kw_local'])
             check(lib().nerf_field_from_features(C.byref(net.encoder.cfg), C.byref(net.net_cfg), ptr(sigma_w), ptr(color_w),

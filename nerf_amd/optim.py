@@ -115,21 +115,24 @@ class TablePipeline(object):
                 self.count_done.synchronize()       # an early count pass may still be writing the old workspace
             self.binned_ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
 
-    def count_early(self, cfg, src, tag, device):
+    def count_early(self, cfg, src, tag, device, on=None):
         """The count + scan passes of bin() need only the points: issued from the FORWARD pass on a side stream they run
         under the field forward (which is bound by random gathers, while the count pass is index arithmetic + an LDS
         histogram) instead of between the backward kernel and the fill.  `tag` identifies the forward whose backward may
-        use the counts; any other backward (a second forward in between, gradient accumulation) counts again."""
+        use the counts; any other backward (a second forward in between, gradient accumulation) counts again.  `on`: the side
+        stream to use instead of the pipeline's own count stream."""
         self.count_tag = None
         if not self.binned_levels or self.binned_pending is not None or self.binned_fallback or src.n_points == 0:
             return
         self._binned_setup(cfg, src.n_points, device)
-        if self.count_stream is None:
-            self.count_stream = torch.cuda.Stream()
+        if on is None:
+            if self.count_stream is None:
+                self.count_stream = torch.cuda.Stream()
+            on = self.count_stream
         ready = torch.cuda.Event()
         ready.record()      # the points exist, and every earlier reader of the workspace (the last update pass) was issued
-        with torch.cuda.stream(self.count_stream):
-            self.count_stream.wait_event(ready)
+        with torch.cuda.stream(on):
+            on.wait_event(ready)
             check(lib().nerf_table_bin_count(C.byref(cfg), C.byref(src), C.byref(self.binned_set), ptr(self.binned_ws),
                                              self.binned_ws.numel(), stream()), 'nerf_table_bin_count')
             self.count_done = torch.cuda.Event()
@@ -165,6 +168,38 @@ class TablePipeline(object):
             check(lib().nerf_table_bin_levels(C.byref(cfg), C.byref(src), C.byref(self.binned_set), ptr(dfeat), stride,
                                               col_arr, ptr(self.binned_ws), self.binned_ws.numel(), stream()),
                   'nerf_table_bin_levels')
+        self.binned_pending = (src.n_points, self.binned_ws.numel())
+        self.binned_keep = (src, dfeat, stride, cols, keepalive)
+
+    # ---- the same, with the fill issued range by range (level sharding: the gradient rows arrive group by group) ----
+    def bin_ranges_start(self, cfg, src, dfeat, stride, cols, dtable, keepalive=None, tag=None):
+        """Prepare a bin pass over all points of `src` whose fill will be issued with bin_range() for whole-chunk point
+        ranges, as their rows of `dfeat` become complete; the count + scan passes run here unless count_early() already ran
+        them for this forward (`tag`).  Returns False when the fast path is not available (no binned levels, or a second
+        backward before step()): the caller then calls bin() once everything has arrived."""
+        if not self.binned_levels or self.binned_pending is not None or self.binned_fallback:
+            return False
+        counted = getattr(self, 'count_tag', None)
+        self.count_tag = None
+        self._binned_setup(cfg, src.n_points, dfeat.device)
+        if self.count_done is not None:
+            torch.cuda.current_stream().wait_event(self.count_done)
+        if not (tag is not None and counted == (tag, src.n_points, self.binned_ws.data_ptr())):
+            check(lib().nerf_table_bin_count(C.byref(cfg), C.byref(src), C.byref(self.binned_set), ptr(self.binned_ws),
+                                             self.binned_ws.numel(), stream()), 'nerf_table_bin_count')
+        col_arr = (C.c_int32 * len(self.binned_levels))(*[int(cols[l]) for l in self.binned_levels])
+        self._ranged = (cfg, src, dfeat, stride, col_arr, cols, keepalive)
+        return True
+
+    def bin_range(self, p_begin, p_end):
+        cfg, src, dfeat, stride, col_arr, _cols, _alive = self._ranged
+        check(lib().nerf_table_bin_fill_range(C.byref(cfg), C.byref(src), C.byref(self.binned_set), ptr(dfeat), stride, col_arr,
+                                              ptr(self.binned_ws), self.binned_ws.numel(), int(p_begin), int(p_end), stream()),
+              'nerf_table_bin_fill_range')
+
+    def bin_ranges_finish(self):
+        cfg, src, dfeat, stride, _col_arr, cols, keepalive = self._ranged
+        self._ranged = None
         self.binned_pending = (src.n_points, self.binned_ws.numel())
         self.binned_keep = (src, dfeat, stride, cols, keepalive)
 

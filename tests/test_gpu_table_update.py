@@ -222,6 +222,54 @@ def test_early_count_pass_changes_nothing(interleave, monkeypatch):
     assert float(((p1 - p0).abs() > 1e-5).float().mean()) < 1e-2
 
 
+def test_ranged_fill_equals_one_fill():
+    """nerf_table_bin_fill_range over [0, 2 chunks), [2 chunks, M) (M not a multiple of the chunk) after one count pass
+    against nerf_table_bin_levels: the same Adam step up to the summation order inside a bin; ranges that are not whole
+    chunks are refused."""
+    from nerf_amd._lib import check, lib, ptr, stream
+    from nerf_amd.nets import make_point_src
+    enc = _grid(16, 2, 19)
+    cfg = enc.cfg
+    levels = [15, 12, 9]
+    ls = _level_set(levels)
+    M = 3 * 16384 + 777
+    g = torch.Generator(device='cuda').manual_seed(5)
+    x = torch.rand(M, 3, device='cuda', generator=g) * 2 - 1
+    src = make_point_src(outer_bound=1.0, x=x, n_points=M)
+    dfeat = torch.randn(M, 8, device='cuda', generator=g) * 1e-3
+    cols = (C.c_int32 * 3)(0, 2, 4)
+    n = int(lib().nerf_table_bin_workspace_bytes(C.byref(cfg), C.byref(ls), M))
+
+    def step(ranged):
+        ws = torch.zeros(n, dtype=torch.uint8, device='cuda')
+        if ranged:
+            check(lib().nerf_table_bin_count(C.byref(cfg), C.byref(src), C.byref(ls), ptr(ws), n, stream()), 'count')
+            for a, b in ((2 * 16384, M), (0, 2 * 16384)):       # any order
+                check(lib().nerf_table_bin_fill_range(C.byref(cfg), C.byref(src), C.byref(ls), ptr(dfeat), 8, cols, ptr(ws), n,
+                                                      a, b, stream()), 'fill_range')
+        else:
+            check(lib().nerf_table_bin_levels(C.byref(cfg), C.byref(src), C.byref(ls), ptr(dfeat), 8, cols, ptr(ws), n,
+                                              stream()), 'bin')
+        p = enc.params.detach().clone()
+        m, v = torch.zeros_like(p), torch.zeros_like(p)
+        check(lib().nerf_table_update_binned(C.byref(cfg), C.byref(ls), M, ptr(ws), n, ptr(p), ptr(m), ptr(v), 1e-2, 0.9, 0.99,
+                                             1e-8, 0.0, 1, 1.0, stream()), 'update')
+        torch.cuda.synchronize()
+        return p, m, v
+
+    p1, m1, v1 = step(True)
+    p0, m0, v0 = step(False)
+    assert float(m0.abs().max()) > 0
+    assert float((m1 - m0).norm() / m0.norm()) < 1e-5
+    assert float((v1 - v0).norm() / v0.norm()) < 1e-5
+    assert float((p1 - p0).abs().max()) <= 2e-2 and float(((p1 - p0).abs() > 1e-6).float().mean()) < 1e-3
+    ws = torch.zeros(n, dtype=torch.uint8, device='cuda')
+    assert lib().nerf_table_bin_fill_range(C.byref(cfg), C.byref(src), C.byref(ls), ptr(dfeat), 8, cols, ptr(ws), n, 100, M,
+                                           stream()) != 0
+    assert lib().nerf_table_bin_fill_range(C.byref(cfg), C.byref(src), C.byref(ls), ptr(dfeat), 8, cols, ptr(ws), n, 0, 16384 + 5,
+                                           stream()) != 0
+
+
 def test_update_on_a_foreign_workspace_stays_in_bounds():
     """nerf_table_update_binned on a workspace that nerf_table_bin_levels never filled (random bytes): the result is
     garbage, but every read and write stays inside the workspace and the listed levels (no GPU fault, levels outside
