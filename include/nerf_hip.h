@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NERF_ABI_VERSION 1
+#define NERF_ABI_VERSION 2
 #define NERF_MAX_LEVELS 32
 #define NERF_MAX_SEGMENTS 16
 #define NERF_MAX_SAMPLES 512 /* per-ray kernels keep one ray in LDS */
@@ -79,6 +79,12 @@ typedef struct NerfPointSrc {
     int64_t z_stride;
     float inner_bound;
     float outer_bound;
+    /* Traversal hint for the forward kernels (mode 1 only; 0 = off, else must be 32 and divide the ray count): a
+     * wavefront takes ONE sample index of 32 consecutive rays instead of 32 consecutive samples of one ray. Inputs and
+     * outputs keep their [ray][sample] places, results are bit-identical; it pays when consecutive rays are
+     * neighbouring pixels (inference.py:54-94), whose samples share hash-grid cells. Ignored by every other kernel. */
+    int32_t ray_block;
+    int32_t reserved_;
 } NerfPointSrc;
 
 /* A subset of hash-grid levels, for the level-sharded (multi-GPU) table: column block i of a

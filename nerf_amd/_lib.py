@@ -29,7 +29,8 @@ class NerfNetCfg(C.Structure):
 class NerfPointSrc(C.Structure):
     _fields_ = [('mode', C.c_int32), ('n_samples', C.c_int32), ('n_points', C.c_int64), ('x', C.c_void_p),
                 ('d', C.c_void_p), ('n', C.c_void_p), ('rays_o', C.c_void_p), ('rays_d', C.c_void_p),
-                ('z', C.c_void_p), ('z_stride', C.c_int64), ('inner_bound', C.c_float), ('outer_bound', C.c_float)]
+                ('z', C.c_void_p), ('z_stride', C.c_int64), ('inner_bound', C.c_float), ('outer_bound', C.c_float),
+                ('ray_block', C.c_int32), ('reserved_', C.c_int32)]
 
 
 class NerfLevelSet(C.Structure):
@@ -172,7 +173,7 @@ def lib():
             fn.argtypes = args
             launches = res is _I and name not in ('nerf_abi_version',)
             setattr(l, name, _Timed(name, fn) if launches else fn)
-        if l.nerf_abi_version() != 1:
+        if l.nerf_abi_version() != 2:
             raise RuntimeError('libnerf_hip.so ABI version mismatch')
         _lib = l
     return _lib

@@ -40,7 +40,14 @@ __global__ __launch_bounds__(kFwdMaxThreads) void field_fwd_kernel(GridDev g, Ne
 
     for (int64_t tile = (int64_t)blockIdx.x * waves_per_block + wave; tile < n_tiles;
          tile += (int64_t)gridDim.x * waves_per_block) {
-        const int64_t p_raw = tile * kTilePts + l31;
+        int64_t p_raw = tile * kTilePts + l31;
+        if (src.ray_block) {
+            // traversal hint (nerf_hip.h): this tile is sample `smp` of the 32 rays of block `blk`
+            const int64_t per_blk = (int64_t)kTilePts * src.n_samples;
+            const int64_t blk = (int64_t)((uint64_t)tile / (uint32_t)src.n_samples);
+            const int smp = (int)(tile - blk * src.n_samples);
+            p_raw = blk * per_blk + (int64_t)l31 * src.n_samples + smp;
+        }
         const bool valid = p_raw < M;
         const int64_t p = valid ? p_raw : M - 1;
         PointIn q = {};
@@ -438,6 +445,11 @@ int nerf_check_src(const char* fn, const NerfPointSrc* src, bool with_color) {
             nerf_set_error("%s: rays mode needs rays_o, rays_d, z and n_points = rays * n_samples", fn); return NERF_EINVAL;
         }
     } else { nerf_set_error("%s: unknown point-source mode", fn); return NERF_EINVAL; }
+    if (src->ray_block != 0 && (src->ray_block != kTilePts || src->mode != 1 ||
+                                src->n_points % ((int64_t)kTilePts * src->n_samples))) {
+        nerf_set_error("%s: ray_block must be 0, or %d in rays mode with a multiple of %d rays", fn, kTilePts, kTilePts);
+        return NERF_EINVAL;
+    }
     if (!(src->outer_bound > 0.f)) { nerf_set_error("%s: outer_bound must be positive", fn); return NERF_EINVAL; }
     return 0;
 }
@@ -517,6 +529,7 @@ int nerf_density_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const float
     rc = nerf_check_src("nerf_density_fwd", src, false);
     if (rc) return rc;
     NERF_REQUIRE(table && sigma_params && sigma, "null pointer");
+    NERF_REQUIRE(!(src->ray_block && x_hashtable), "ray_block is for passes that keep no x_hashtable");
     if (src->n_points == 0) return 0;
     return launch_fwd<false, false>(grid, net, table, sigma_params, nullptr, nullptr, 0, src, sigma, nullptr, x_hashtable,
                                     nullptr, nullptr, stream);
@@ -531,6 +544,7 @@ int nerf_field_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const float* 
     if (rc) return rc;
     NERF_REQUIRE(table && sigma_params && color_params && sigma && rgb, "null pointer");
     NERF_REQUIRE(net->latent_dim == 0 || (latent_emb && n_images > 0), "latent embedding missing");
+    NERF_REQUIRE(!(src->ray_block && x_hashtable), "ray_block is for passes that keep no x_hashtable");
     if (src->n_points == 0) return 0;
     return launch_fwd<true, false>(grid, net, table, sigma_params, color_params, latent_emb, n_images, src, sigma, rgb,
                                    x_hashtable, xyz, nullptr, stream);

@@ -18,8 +18,9 @@ from ._lib import NerfGridCfg, NerfNetCfg, NerfPointSrc, check, f32, i64, lib, p
 
 
 def make_point_src(outer_bound, x=None, d=None, n=None, rays_o=None, rays_d=None, z=None, z_stride=0, n_samples=0,
-                   n_points=0, inner_bound=0.0):
+                   n_points=0, inner_bound=0.0, ray_block=0):
     s = NerfPointSrc()
+    s.ray_block = int(ray_block)
     s.mode = 0 if x is not None else 1
     s.n_samples = int(n_samples)
     s.n_points = int(n_points)

@@ -110,6 +110,16 @@ class NerfRenderer(nn.Module):
         if len(self.z_bounds) != len(self.steps_firstpass) + 1:
             raise ValueError('len(z_bounds) must be len(steps) + 1')
         self._tables = {}
+        # set by the Inferencer while it renders pixel-ordered rays: consecutive rays are neighbouring pixels, so the field
+        # kernels walk the samples ray-block-wise (NerfPointSrc.ray_block: same results, far fewer distinct cache lines)
+        self.coherent_rays = False
+
+    def _ray_block(self, n_rays):
+        if not self.coherent_rays or n_rays % 32 or torch.is_grad_enabled():
+            return {}
+        if not isinstance(self.model, NeRFNetwork) or self.model._sharded():
+            return {}
+        return {'ray_block': 32}
 
     # ---- host-side constant tables (ray independent; built with CPU torch so they are bit-equal
     #      to what the reference's linspace / pow produce) -------------------------------------
@@ -230,7 +240,8 @@ class NerfRenderer(nn.Module):
         Sc = zlog_c.shape[0]
         if isinstance(self.model, NeRFNetwork):
             sigmas, _ = self.model.density_kw(dict(outer_bound=self.outer_bound, rays_o=ro, rays_d=rd, z=z_c, z_stride=0,
-                                                   n_samples=Sc, n_points=N * Sc, inner_bound=self.inner_bound))
+                                                   n_samples=Sc, n_points=N * Sc, inner_bound=self.inner_bound,
+                                                   **self._ray_block(N)))
             sigmas = sigmas.view(N, Sc)
         else:
             z_vals_log, z_vals = self.get_uniform_z_vals(ro, rd, self.steps_firstpass)
@@ -291,7 +302,7 @@ class NerfRenderer(nn.Module):
         if lean:
             sigmas, rgbs = self.model.field_nograd(
                 dict(outer_bound=self.outer_bound, rays_o=rays_o, rays_d=rays_d, z=z_vals, z_stride=Sf, n_samples=Sf,
-                     n_points=N * Sf, n=i64(n).reshape(-1), inner_bound=self.inner_bound))
+                     n_points=N * Sf, n=i64(n).reshape(-1), inner_bound=self.inner_bound, **self._ray_block(N)))
             sigmas, rgbs, xyzs, x_hashtable = sigmas.view(N, Sf), rgbs.view(N, Sf, 3), None, None
         elif isinstance(self.model, NeRFNetwork):
             nn_ = i64(n).reshape(-1)

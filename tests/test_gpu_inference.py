@@ -233,3 +233,58 @@ def test_sharded_inference_and_extraction_match_single_process():
         for k, v in want.items():
             assert got[r][k].shape == v.shape, (r, k, got[r][k].shape, v.shape)
             assert np.array_equal(got[r][k], v), (r, k)
+
+
+def test_ray_block_traversal_is_bit_identical():
+    """NerfPointSrc.ray_block (a wavefront takes one sample index of 32 consecutive rays) only changes which lane evaluates
+    which point: sigma and rgb of nerf_density_fwd / nerf_field_fwd and a whole render_image must be BIT-equal to the
+    default traversal; a ray count that is not a multiple of 32, points mode and a kept x_hashtable are refused."""
+    import ctypes as C
+    from nerf_amd._lib import lib, ptr, stream
+    from nerf_amd.inference import Inferencer
+    from nerf_amd.nets import make_point_src
+    net, ora, Rg, Ro, _ = _setup()
+    g = torch.Generator(device='cuda').manual_seed(11)
+    N, S = 96, 40
+    ro = torch.randn(N, 3, device='cuda', generator=g) * 0.3
+    rd = torch.randn(N, 3, device='cuda', generator=g)
+    z = torch.rand(N, S, device='cuda', generator=g).sort(dim=1).values * 3 + 1.6
+    nidx = torch.randint(0, net.N, (N,), device='cuda', generator=g)
+    kw = dict(outer_bound=2.5, rays_o=ro, rays_d=rd, z=z, z_stride=S, n_samples=S, n_points=N * S, n=nidx, inner_bound=2.0)
+    s0, c0 = net.field_nograd(kw)
+    s1, c1 = net.field_nograd(dict(kw, ray_block=32))
+    assert torch.equal(s0, s1) and torch.equal(c0, c1) and float(s0.abs().max()) > 0
+    d0, _ = net.density_kw({k: v for k, v in kw.items() if k != 'n'})
+    d1, _ = net.density_kw(dict({k: v for k, v in kw.items() if k != 'n'}, ray_block=32))
+    assert torch.equal(d0, d1)
+    # refused shapes
+    sig = torch.empty(N * S, device='cuda')
+    xh = torch.empty(N * S, net.encoder.n_output_dims, device='cuda')
+
+    def density(src, xh_ptr):
+        return lib().nerf_density_fwd(C.byref(net.encoder.cfg), C.byref(net.net_cfg), ptr(net.encoder.params),
+                                      ptr(net.sigma_net.params), C.byref(src), ptr(sig), xh_ptr, stream())
+    ok = {k: v for k, v in kw.items() if k != 'n'}
+    assert density(make_point_src(**dict(ok, ray_block=32)), None) == 0
+    assert density(make_point_src(**dict(ok, ray_block=32)), ptr(xh)) != 0
+    assert density(make_point_src(**dict(ok, ray_block=16)), None) != 0
+    odd = dict(ok, rays_o=ro[:50], rays_d=rd[:50], z=z[:50], n_points=50 * S, ray_block=32)
+    assert density(make_point_src(**odd), None) != 0
+    pts = make_point_src(outer_bound=2.5, x=torch.rand(64, 3, device='cuda'), n_points=64, ray_block=32)
+    assert density(pts, None) != 0
+    torch.cuda.synchronize()
+    # a whole image through the Inferencer: the hint on (default) against off
+    from test_gpu_parity import _batch
+    n, h, w, K, E, bg, noise, gt = _batch(5, 640)
+    c = lambda t: t.cuda()
+    args = [c(t).reshape(20, 32, *t.shape[1:]) for t in (n, h, w, K, E)]
+    inf = Inferencer(Rg, 256, 0, 0, VAR_NPY, VAR_PCD, AREA, [1], 20)
+    img1, inv1 = inf.render_image(*args, noise=c(noise))
+    import nerf_amd.inference as inference_mod
+    old = inference_mod.COHERENT_RAYS
+    inference_mod.COHERENT_RAYS = False
+    try:
+        img0, inv0 = inf.render_image(*args, noise=c(noise))
+    finally:
+        inference_mod.COHERENT_RAYS = old
+    assert np.array_equal(img0, img1) and np.array_equal(inv0, inv1) and Rg.coherent_rays is False
