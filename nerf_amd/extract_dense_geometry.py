@@ -2,15 +2,21 @@
 camera-frustum occupancy mask, then bulk field queries over voxel_res^3 voxel centres, keeping the
 points with sigma > thresh.  Differences, on purpose:
 
-* voxel coordinates are generated on the GPU per batch (the reference builds them on the CPU and copies,
-  :73-79) and results stay on the GPU until the end (the reference concatenates on the CPU per batch, :92-95);
+* voxel coordinates are generated on the GPU (the reference builds them on the CPU and copies, :73-79), the mask
+  is applied to all voxels at once, the field runs over batches of VALID voxels in 4 x 4 x 2 brick order, and the
+  threshold is one selection at the end (the reference masks, queries, thresholds and concatenates on the CPU per
+  batch, :66-95): same points, same order, no host round trip per batch;
 * under torch.distributed each rank takes a contiguous slab of the voxel index range and the
   variable-length results are all_gathered once;
 * the open3d wrapper ``generate_dense_pointcloud`` is out of scope (open3d is not part of the hot path).
 The field evaluation itself is ``NeRFNetwork.field_nograd`` -> nerf_field_fwd (HIP) without the feature rows."""
+import os
+
 import torch
 
 from . import parallel
+
+BRICK_ORDER = os.environ.get('NERF_EXTRACT_BRICKS', '1') != '0'
 
 
 class ExtractDenseGeometry():
@@ -61,28 +67,46 @@ class ExtractDenseGeometry():
         voxels = torch.linspace(-1 + 1 / R, 1 - 1 / R, R).to(dev)     # built on the CPU like the reference, then moved
         num_samples = R ** 3
         start, stop = parallel.shard_range(num_samples, parallel.rank(), parallel.world_size())
-        points, colors = [], []
+        # The reference masks, queries and thresholds batch by batch (:66-95), three host round trips per batch.  Here the mask
+        # lookup of :80-82 is made per axis (the same float arithmetic on the same R values) and expanded to all voxels at
+        # once, ONE nonzero() lists the valid voxels of this rank's slab, the field runs over batches of valid voxels only,
+        # and one selection at the end applies the threshold: the same points in the same (ascending voxel) order.
+        ax = [((voxels + 1) / 2 * mask.shape[k]).to(torch.int64) for k in range(3)]
+        keep = mask[ax[0][:, None, None], ax[1][None, :, None], ax[2][None, None, :]]          # [R, R, R] bool
+        if start > 0 or stop < num_samples:
+            flat = keep.reshape(-1).clone()
+            flat[:start] = False
+            flat[stop:] = False
+            keep = flat.view(R, R, R)
+        # valid voxels in 4 x 4 x 2 BRICK order (a wavefront of the field kernel takes 32 consecutive points: a brick shares
+        # far more hash-grid cells than a 32-voxel line); un-done by the final sort of the few selected points
+        bricks = BRICK_ORDER and R % 4 == 0
+        if bricks:
+            canon = torch.arange(num_samples, device=dev).view(R // 4, 4, R // 4, 4, R // 2, 2).permute(0, 2, 4, 1, 3, 5)
+            idx = canon.reshape(-1)[keep.view(R // 4, 4, R // 4, 4, R // 2, 2).permute(0, 2, 4, 1, 3, 5).reshape(-1)]
+        else:
+            idx = keep.reshape(-1).nonzero().squeeze(1)
+        P = int(idx.numel())
+        sig = torch.empty(P, device=dev)
+        rgb = torch.empty(P, 3, device=dev)
         dir_z = torch.tensor([0.0, 0.0, 1.0], device=dev)
-        for a in range(start, stop, self.batch_size):
-            b = min(stop, a + self.batch_size)
-            n = torch.arange(a, b, device=dev)
-            x = voxels[torch.div(n, R ** 2, rounding_mode='floor')]
-            y = voxels[torch.div(n, R, rounding_mode='floor') % R]
-            z = voxels[n % R]
-            keep = mask[((x + 1) / 2 * mask.shape[0]).to(torch.int64), ((y + 1) / 2 * mask.shape[1]).to(torch.int64),
-                        ((z + 1) / 2 * mask.shape[2]).to(torch.int64)]
-            xyz = torch.stack((x, y, z), dim=-1)[keep].contiguous()
-            if xyz.shape[0] > 0:
-                dirs = dir_z[None].expand(xyz.shape[0], 3).contiguous()
-                n_i = torch.zeros(xyz.shape[0], dtype=torch.int64, device=dev)
-                # field_nograd: no autograd node and no x_hashtable rows (160 B/point the reference's forward
-                # returns at :88 and extraction discards)
-                sigmas, rgbs = self.model.field_nograd(dict(outer_bound=self.outer_bound, x=xyz, d=dirs, n=n_i,
-                                                            n_points=xyz.shape[0]))
-                sel = sigmas > self.thresh
-                points.append(xyz[sel])
-                colors.append(rgbs[sel])
-        cat = lambda xs: torch.cat(xs, dim=0) if xs else torch.zeros((0, 3), device=dev)
-        pts = parallel.gather_varlen(cat(points))
-        col = parallel.gather_varlen(cat(colors))
+        coords = lambda n: torch.stack((voxels[torch.div(n, R ** 2, rounding_mode='floor')],
+                                        voxels[torch.div(n, R, rounding_mode='floor') % R], voxels[n % R]), dim=-1)
+        for a in range(0, P, self.batch_size):
+            b = min(P, a + self.batch_size)
+            xyz = coords(idx[a:b]).contiguous()
+            dirs = dir_z[None].expand(b - a, 3).contiguous()
+            n_i = torch.zeros(b - a, dtype=torch.int64, device=dev)
+            # field_nograd: no autograd node and no x_hashtable rows (160 B/point the reference's forward
+            # returns at :88 and extraction discards)
+            sigmas, rgbs = self.model.field_nograd(dict(outer_bound=self.outer_bound, x=xyz, d=dirs, n=n_i, n_points=b - a))
+            sig[a:b] = sigmas
+            rgb[a:b] = rgbs
+        sel = sig > self.thresh
+        chosen, colors = idx[sel], rgb[sel]
+        if bricks:
+            chosen, order = torch.sort(chosen)
+            colors = colors[order]
+        pts = parallel.gather_varlen(coords(chosen).reshape(-1, 3))
+        col = parallel.gather_varlen(colors)
         return pts.cpu(), col.cpu()
