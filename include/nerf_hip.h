@@ -79,8 +79,9 @@ typedef struct NerfPointSrc {
     int64_t z_stride;
     float inner_bound;
     float outer_bound;
-    /* Traversal hint for the forward kernels (mode 1 only; 0 = off, else must be 32 and divide the ray count): a
-     * wavefront takes ONE sample index of 32 consecutive rays instead of 32 consecutive samples of one ray. Inputs and
+    /* Traversal hint for the forward kernels (mode 1 only; 0 = off, else 32, 16 or 8, dividing the ray count): a
+     * wavefront takes 1 (2, 4) consecutive sample indices of 32 (16, 8) consecutive rays instead of 32 consecutive
+     * samples of one ray (n_samples must be a multiple of 1, 2, 4). Inputs and
      * outputs keep their [ray][sample] places, results are bit-identical; it pays when consecutive rays are
      * neighbouring pixels (inference.py:54-94), whose samples share hash-grid cells. Ignored by every other kernel. */
     int32_t ray_block;

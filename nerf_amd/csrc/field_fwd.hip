@@ -43,10 +43,12 @@ __global__ __launch_bounds__(kFwdMaxThreads) void field_fwd_kernel(GridDev g, Ne
         int64_t p_raw = tile * kTilePts + l31;
         if (src.ray_block) {
             // traversal hint (nerf_hip.h): this tile is sample `smp` of the 32 rays of block `blk`
-            const int64_t per_blk = (int64_t)kTilePts * src.n_samples;
-            const int64_t blk = (int64_t)((uint64_t)tile / (uint32_t)src.n_samples);
-            const int smp = (int)(tile - blk * src.n_samples);
-            p_raw = blk * per_blk + (int64_t)l31 * src.n_samples + smp;
+            // (ray_block = 32: one sample of 32 rays; 16 / 8: two / four consecutive samples of 16 / 8 rays)
+            const int rb = src.ray_block, sp = kTilePts / rb;           // rays and samples of a tile
+            const uint32_t tiles_per_blk = (uint32_t)(src.n_samples / sp);
+            const int64_t blk = (int64_t)((uint64_t)tile / tiles_per_blk);
+            const int smp = (int)(tile - blk * tiles_per_blk) * sp + l31 / rb;
+            p_raw = (blk * rb + (l31 & (rb - 1))) * src.n_samples + smp;
         }
         const bool valid = p_raw < M;
         const int64_t p = valid ? p_raw : M - 1;
@@ -445,10 +447,14 @@ int nerf_check_src(const char* fn, const NerfPointSrc* src, bool with_color) {
             nerf_set_error("%s: rays mode needs rays_o, rays_d, z and n_points = rays * n_samples", fn); return NERF_EINVAL;
         }
     } else { nerf_set_error("%s: unknown point-source mode", fn); return NERF_EINVAL; }
-    if (src->ray_block != 0 && (src->ray_block != kTilePts || src->mode != 1 ||
-                                src->n_points % ((int64_t)kTilePts * src->n_samples))) {
-        nerf_set_error("%s: ray_block must be 0, or %d in rays mode with a multiple of %d rays", fn, kTilePts, kTilePts);
-        return NERF_EINVAL;
+    if (src->ray_block != 0) {
+        const int rb = src->ray_block;
+        if ((rb != 8 && rb != 16 && rb != 32) || src->mode != 1 || src->n_points % ((int64_t)rb * src->n_samples) ||
+            src->n_samples % (kTilePts / rb)) {
+            nerf_set_error("%s: ray_block must be 0, or 8 / 16 / 32 in rays mode with a multiple of that many rays and a "
+                           "multiple of 4 / 2 / 1 samples", fn);
+            return NERF_EINVAL;
+        }
     }
     if (!(src->outer_bound > 0.f)) { nerf_set_error("%s: outer_bound must be positive", fn); return NERF_EINVAL; }
     return 0;

@@ -13,6 +13,7 @@ from ._lib import check, f32, lib, ptr, stream
 
 COHERENT_RAYS = os.environ.get('NERF_COHERENT_RAYS', '1') != '0'
 PIXEL_TILES = os.environ.get('NERF_PIXEL_TILES', '1') != '0'
+SUPER_TILES = os.environ.get('NERF_PIXEL_SUPERTILES', '1') != '0'
 
 
 def _whole_table(fn):
@@ -66,8 +67,13 @@ class Inferencer(object):
         if key not in cache:
             H, W = shape[-2], shape[-1]
             lead = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
-            idx = torch.arange(lead * H * W, device=device).reshape(lead, H // 4, 4, W // 8, 8)
-            cache[key] = idx.permute(0, 1, 3, 2, 4).reshape(-1)
+            if SUPER_TILES and H % 32 == 0 and W % 32 == 0:
+                # tiles in 32 x 32 pixel squares (8 x 4 tiles): the ray blocks in flight at one time cover a compact region
+                idx = torch.arange(lead * H * W, device=device).reshape(lead, H // 32, 8, 4, W // 32, 4, 8)
+                cache[key] = idx.permute(0, 1, 4, 2, 5, 3, 6).reshape(-1)
+            else:
+                idx = torch.arange(lead * H * W, device=device).reshape(lead, H // 4, 4, W // 8, 8)
+                cache[key] = idx.permute(0, 1, 3, 2, 4).reshape(-1)
         return cache[key]
 
     def _lean(self):

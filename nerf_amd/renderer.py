@@ -12,6 +12,7 @@ injected for bit-exact index parity) and ``generator``.
 """
 import ctypes as C
 import math as m
+import os
 
 import torch
 import torch.nn as nn
@@ -96,6 +97,9 @@ class _CompositeLossFn(torch.autograd.Function):
         return (dsig, drgb) + (None,) * 8
 
 
+RAY_BLOCK = int(os.environ.get('NERF_RAY_BLOCK', '32'))
+
+
 class NerfRenderer(nn.Module):
     def __init__(self, model, inner_bound, outer_bound, z_bounds, steps_firstpass, steps_importance, alpha_importance):
         super().__init__()
@@ -119,7 +123,7 @@ class NerfRenderer(nn.Module):
             return {}
         if not isinstance(self.model, NeRFNetwork) or self.model._sharded():
             return {}
-        return {'ray_block': 32}
+        return {'ray_block': RAY_BLOCK}
 
     # ---- host-side constant tables (ray independent; built with CPU torch so they are bit-equal
     #      to what the reference's linspace / pow produce) -------------------------------------

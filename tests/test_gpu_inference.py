@@ -236,7 +236,7 @@ def test_sharded_inference_and_extraction_match_single_process():
 
 
 def test_ray_block_traversal_is_bit_identical():
-    """NerfPointSrc.ray_block (a wavefront takes one sample index of 32 consecutive rays) only changes which lane evaluates
+    """NerfPointSrc.ray_block (a wavefront takes 1 / 2 / 4 sample indices of 32 / 16 / 8 consecutive rays) only changes which lane evaluates
     which point: sigma and rgb of nerf_density_fwd / nerf_field_fwd and a whole render_image must be BIT-equal to the
     default traversal; a ray count that is not a multiple of 32, points mode and a kept x_hashtable are refused."""
     import ctypes as C
@@ -252,11 +252,13 @@ def test_ray_block_traversal_is_bit_identical():
     nidx = torch.randint(0, net.N, (N,), device='cuda', generator=g)
     kw = dict(outer_bound=2.5, rays_o=ro, rays_d=rd, z=z, z_stride=S, n_samples=S, n_points=N * S, n=nidx, inner_bound=2.0)
     s0, c0 = net.field_nograd(kw)
-    s1, c1 = net.field_nograd(dict(kw, ray_block=32))
-    assert torch.equal(s0, s1) and torch.equal(c0, c1) and float(s0.abs().max()) > 0
     d0, _ = net.density_kw({k: v for k, v in kw.items() if k != 'n'})
-    d1, _ = net.density_kw(dict({k: v for k, v in kw.items() if k != 'n'}, ray_block=32))
-    assert torch.equal(d0, d1)
+    assert float(s0.abs().max()) > 0
+    for rb in (32, 16, 8):      # 1, 2, 4 consecutive samples of 32, 16, 8 rays per wavefront
+        s1, c1 = net.field_nograd(dict(kw, ray_block=rb))
+        assert torch.equal(s0, s1) and torch.equal(c0, c1)
+        d1, _ = net.density_kw(dict({k: v for k, v in kw.items() if k != 'n'}, ray_block=rb))
+        assert torch.equal(d0, d1)
     # refused shapes
     sig = torch.empty(N * S, device='cuda')
     xh = torch.empty(N * S, net.encoder.n_output_dims, device='cuda')
@@ -267,7 +269,7 @@ def test_ray_block_traversal_is_bit_identical():
     ok = {k: v for k, v in kw.items() if k != 'n'}
     assert density(make_point_src(**dict(ok, ray_block=32)), None) == 0
     assert density(make_point_src(**dict(ok, ray_block=32)), ptr(xh)) != 0
-    assert density(make_point_src(**dict(ok, ray_block=16)), None) != 0
+    assert density(make_point_src(**dict(ok, ray_block=12)), None) != 0
     odd = dict(ok, rays_o=ro[:50], rays_d=rd[:50], z=z[:50], n_points=50 * S, ray_block=32)
     assert density(make_point_src(**odd), None) != 0
     pts = make_point_src(outer_bound=2.5, x=torch.rand(64, 3, device='cuda'), n_points=64, ray_block=32)
