@@ -98,12 +98,14 @@ def train_step(model, renderer, loader, opt, n_rays, it, world):
     else:
         rgb, weights, zs, _ = renderer.render(n, h, w, K, E, color_bg)
         loss, _ = helpers.fused_train_loss(rgb, rgb_gt, weights, zs, lam_dist, 1e-1)
-    loss.backward()
     opt.skip_flag = loss.nonfinite_flag        # Trainer.train_epoch's non-finite guard (device side, no sync)
     if world > 1:
-        skip = [opt._table_param] if opt.table_reduced_by_pipeline() else []
-        parallel.all_reduce_grads([p for g in opt.param_groups for p in g['params']], skip=skip, flags=[opt.skip_flag])
+        skip = lambda: [opt._table_param] if opt.table_reduced_by_pipeline() else []
+        parallel.backward_and_reduce(loss, model, [p for g in opt.param_groups for p in g['params']], skip=skip,
+                                     flags=[opt.skip_flag])
         opt.grad_scale = 1.0 / world
+    else:
+        loss.backward()
     opt.step()
     return loss
 

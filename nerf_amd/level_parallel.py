@@ -443,6 +443,7 @@ class LevelSharding(object):
         recv = torch.empty(W * M * wm, device=dfeat.device, dtype=torch.float32)
         send_blocks, recv_blocks = self._blocks(send, M, self.width), self._blocks(recv, M, [wm] * W)
         work = parallel.all_to_all_blocks(recv_blocks, send_blocks, async_op=True)
+        self._fire_after_last_backward()
         if pipe is not None:
             pipe.begin(dtable)
         binned = list(pipe.binned_levels) if pipe is not None else []
@@ -517,6 +518,8 @@ class LevelSharding(object):
         recv_g = state['recv'][W * grp['a'] * wm:W * grp['b'] * wm]
         send_blocks, recv_blocks = self._blocks(send, m, self.width), self._blocks(recv_g, m, [wm] * W)
         work = parallel.all_to_all_blocks(recv_blocks, send_blocks, async_op=True)
+        if grp is plan['groups'][-1]:
+            self._fire_after_last_backward()
         if wm:
             recv_blocks[r].copy_(send_blocks[r])        # my own points' rows never travel
         state['works'].append((work, grp, recv_blocks))
@@ -528,6 +531,14 @@ class LevelSharding(object):
                 self._scatter_arrived(state, len(state['works']) - 1, binned, dtable)
             self._fill_arrived(state, len(state['works']) - 1, pipe)
         return state
+
+    def _fire_after_last_backward(self):
+        """Hook (parallel.backward_and_reduce): every MLP / latent gradient of this backward pass has been issued and the last
+        d(features) exchange is on its way -- a small collective queued now completes under that exchange and the bin fill."""
+        fn, self.after_last_backward = getattr(self, 'after_last_backward', None), None
+        if fn is not None:
+            self.early_reduces = getattr(self, 'early_reduces', 0) + 1
+            fn()
 
     def _fill_arrived(self, state, upto, pipe):
         """Ranged fill (main stream) of the groups [state['filled'], upto): their exchanges are waited for first."""

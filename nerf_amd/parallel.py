@@ -129,6 +129,37 @@ def all_reduce_grads(params, async_op=False, skip=(), flags=()):
     return handles
 
 
+EARLY_SMALL_REDUCE = os.environ.get('NERF_EARLY_SMALL_REDUCE', '1') != '0'
+
+
+def backward_and_reduce(loss, model, params, skip=(), flags=()):
+    """loss.backward() followed by all_reduce_grads(params, skip, flags) (trainer.py:134 under data parallelism; `skip` may
+    be a callable, evaluated after the backward pass).  With a
+    level-sharded table and direct gradients the small collective is queued from INSIDE the backward pass, right behind the
+    last ray group's d(features) exchange (LevelSharding.after_last_backward): its latency then hides under that exchange
+    and the owner's bin fill instead of standing between the backward pass and the table update, which needs the summed
+    non-finite flag.  One backward per step only (a second one before step() must use all_reduce_grads itself)."""
+    if world_size() == 1:
+        loss.backward()
+        return
+    sh = getattr(model, 'level_sharding', None)
+    early = (EARLY_SMALL_REDUCE and sh is not None and getattr(model, 'direct_grads', False) and model._sharded())
+    box = []
+    _skip = lambda: skip() if callable(skip) else skip      # (may depend on what the backward pass did: evaluated late)
+    if early:
+        sh.after_last_backward = lambda: box.append(all_reduce_grads(params, async_op=True, skip=_skip(), flags=flags))
+    try:
+        loss.backward()
+    finally:
+        if early:
+            sh.after_last_backward = None
+    if box:
+        for h in box[0]:
+            h.wait()
+    else:
+        all_reduce_grads(params, skip=_skip(), flags=flags)
+
+
 def gather_slices(local, total, dim=0):
     """all_gather contiguous slices produced with shard_range back into one tensor of length `total`."""
     world = world_size()

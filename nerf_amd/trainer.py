@@ -117,19 +117,21 @@ class Trainer(object):
         for i in range(iters_per_epoch):
             self.optimizer.zero_grad()
             loss = self.train_step()
-            loss.backward()
             world = parallel.world_size()
             flag = getattr(loss, 'nonfinite_flag', None)
             guarded = flag is not None and hasattr(self.optimizer, 'skip_flag')
             if guarded:
                 self.optimizer.skip_flag = flag      # a non-finite loss drops this step on the device (no host sync)
             if world > 1:
-                skip = [self.optimizer._table_param] if getattr(self.optimizer, 'table_reduced_by_pipeline', lambda: False)() else []
+                skip = lambda: ([self.optimizer._table_param]
+                                if getattr(self.optimizer, 'table_reduced_by_pipeline', lambda: False)() else [])
                 # (the flag is summed with the small gradients: every rank must take the same decision)
-                parallel.all_reduce_grads([p for g in self.optimizer.param_groups for p in g['params']], skip=skip,
-                                          flags=[flag] if guarded else [])
+                parallel.backward_and_reduce(loss, self.model, [p for g in self.optimizer.param_groups for p in g['params']],
+                                             skip=skip, flags=[flag] if guarded else [])
                 if hasattr(self.optimizer, 'grad_scale'):
                     self.optimizer.grad_scale = 1.0 / world
+            else:
+                loss.backward()
             self.optimizer.step()
             if self.scheduler is not None:
                 self.scheduler.step()

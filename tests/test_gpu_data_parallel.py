@@ -52,15 +52,25 @@ def _train(rank, world, log2_T=15):
         opt.zero_grad()
         img, wts, zs, _ = R.render(n, h, w, K, E, bg, noise=noise)
         loss, _ = helpers.fused_train_loss(img, gt, wts, zs, 1e-3, 1e-1)
-        loss.backward()
-        if world > 1:
-            skip = [opt._table_param] if opt.table_reduced_by_pipeline() else []
-            assert skip, 'the table gradient must not need an all-reduce of its own'
-            parallel.all_reduce_grads([p for g in opt.param_groups for p in g['params']], skip=skip)
+        params = [p for g in opt.param_groups for p in g['params']]
+        if world > 1 and int(os.environ.get('NERF_SHARD_GROUPS', '1')) != 1:
+            # trainer.py:134 as the Trainer and bench.py call it: under level sharding the small all-reduce is queued from
+            # inside the backward pass (parallel.backward_and_reduce)
+            parallel.backward_and_reduce(loss, net, params,
+                                         skip=lambda: [opt._table_param] if opt.table_reduced_by_pipeline() else [])
             opt.grad_scale = 1.0 / world
+        else:
+            loss.backward()
+            if world > 1:
+                skip = [opt._table_param] if opt.table_reduced_by_pipeline() else []
+                assert skip, 'the table gradient must not need an all-reduce of its own'
+                parallel.all_reduce_grads(params, skip=skip)
+                opt.grad_scale = 1.0 / world
         opt.step()
     if world > 1:
         assert (net.level_sharding is not None) == (os.environ.get('NERF_TABLE_PARALLEL') != '0')
+        if net.level_sharding is not None and int(os.environ.get('NERF_SHARD_GROUPS', '1')) != 1:
+            assert net.level_sharding.early_reduces == STEPS        # the hook fired once per backward pass
     if log2_T >= 19 and (world == 1 or net.level_sharding is not None):
         # levels 5-7 are hashed and large enough for the binned table update (every rank together owns all three)
         assert world > 1 or net.table_pipeline.binned_levels == [5, 6, 7], net.table_pipeline.binned_levels

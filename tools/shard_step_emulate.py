@@ -104,8 +104,8 @@ def main():
         # two latencies whatever the world -- RCCL's low-latency protocols, not a 2 (W-1)-hop ring)
         skip_ids = {id(p) for p in skip}
         n = sum(p.numel() * 4 for p in params if p is not None and p.grad is not None and id(p) not in skip_ids)
-        on_wire(2.0 * n * (W - 1) / W, False, hops=2)
-        return []
+        h = on_wire(2.0 * n * (W - 1) / W, async_op, hops=2)
+        return [h] if (async_op and h is not None) else []
     parallel.all_reduce_grads = fake_reduce
     out = []
     for r in (range(W) if args.rank < 0 else [args.rank]):

@@ -11,7 +11,7 @@ i=0
 for V in "BASE=1" ${VARIANTS:-}; do
   i=$((i+1))
   echo "== $V"
-  env ${V//,/ } timeout -k 10 300 python tools/shard_step_emulate.py --world $W --steps 20 --single-ms $SINGLE \
+  env ${V//,/ } timeout -k 10 300 python tools/shard_step_emulate.py --world $W --steps 20 --single-ms $SINGLE --latency-us ${LAT:-20} \
       > $OUT/w${W}_v${i}.log 2> $OUT/w${W}_v${i}.err || exit 1
   tail -1 $OUT/w${W}_v${i}.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['max_ms'], d['mean_ms'], d.get('projected_weak_scaling_efficiency'))"
 done
