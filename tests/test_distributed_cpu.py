@@ -73,6 +73,77 @@ def _dp_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+class _FakeSharding(object):
+    """Stands in for LevelSharding in backward_and_reduce: fires the hook from inside the backward pass."""
+    after_last_backward = None
+
+
+def _early_reduce_worker(rank, world, port, q):
+    from nerf_amd import parallel
+    _init(rank, world, port)
+    torch.manual_seed(3)
+    w_ = torch.nn.Parameter(torch.randn(5, 3))
+    b_ = torch.nn.Parameter(torch.randn(3))
+    big = torch.nn.Parameter(torch.randn(4))        # stands for the table: reduced elsewhere, skipped here
+    x = torch.arange(10.0).reshape(2, 5) + rank
+    sh = _FakeSharding()
+
+    class Model(object):
+        level_sharding, direct_grads = sh, True
+
+        def _sharded(self):
+            return True
+
+    class Fire(torch.autograd.Function):            # the place _ShardedFieldFn.backward calls the hook from
+        @staticmethod
+        def forward(ctx, t):
+            return t.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            w_.grad = x.t() @ g                     # "direct gradients": written by the backward pass itself
+            b_.grad = g.sum(0)
+            fn, sh.after_last_backward = sh.after_last_backward, None
+            assert fn is not None
+            fn()
+            return None
+
+    seen = []
+    orig = parallel.all_reduce_grads
+    parallel.all_reduce_grads = lambda *a, **k: (seen.append(k.get('async_op', False)), orig(*a, **k))[1]
+    out = Fire.apply(x @ w_.detach().requires_grad_() + b_.detach())
+    big.grad = torch.ones(4) * (rank + 1)
+    flag = torch.tensor([float(rank)])
+    parallel.backward_and_reduce(out.sum(), Model(), [w_, b_, big], skip=lambda: [big], flags=[flag])
+    assert seen == [True], seen                     # queued once, asynchronously, from inside the backward pass
+    assert sh.after_last_backward is None and float(flag) == sum(range(world))
+    assert torch.equal(big.grad, torch.ones(4) * (rank + 1))        # skipped
+    want_w = sum((torch.arange(10.0).reshape(2, 5) + r).t() @ torch.ones(2, 3) for r in range(world))
+    assert torch.allclose(w_.grad, want_w) and torch.allclose(b_.grad, torch.full((3,), 2.0 * world))
+    # without a sharded model: plain backward, then the synchronous reduce
+    seen.clear()
+    v = torch.nn.Parameter(torch.ones(3) * (rank + 1))
+    parallel.backward_and_reduce((v * v).sum(), object(), [v], flags=[])
+    assert seen == [False] and torch.allclose(v.grad, torch.full((3,), 2.0 * sum(r + 1 for r in range(world))))
+    if rank == 0:
+        q.put('ok')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_backward_and_reduce_queues_the_small_collective_from_the_backward_pass():
+    """parallel.backward_and_reduce over gloo, two ranks: the hook fires inside backward(), the collective is asynchronous,
+    `skip` is evaluated late, the flag is summed with the gradients; a model without level sharding takes the plain path."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_early_reduce_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    assert q.get(timeout=300) == 'ok'
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+
+
 def test_data_parallel_gradients_match_single_process():
     """mean-over-rays loss: all-reduced (SUM) shard gradients / world == full-batch gradients."""
     ctx = mp.get_context('spawn')
