@@ -463,14 +463,17 @@ int nerf_check_src(const char* fn, const NerfPointSrc* src, bool with_color) {
 // The forward kernels walk the tiles with a grid-sized stride, so the grid is what the chip holds at once: `per_cu`
 // resident workgroups per CU (registers and LDS, from the occupancy query) -- a larger grid runs as a full round of
 // workgroups followed by a partly filled one.
-static unsigned fwd_grid(int64_t n_points, int per_cu, int waves_per_block, bool color) {
+static unsigned fwd_grid(int64_t n_points, int per_cu, int waves_per_block, bool color, bool coherent) {
     const int64_t tiles = ceil_div64(n_points, kTilePts);
     static const int forced = getenv("NERF_FWD_BLOCKS_PER_CU") ? atoi(getenv("NERF_FWD_BLOCKS_PER_CU")) : 0;
     static const int forced_d = getenv("NERF_DENSITY_BLOCKS_PER_CU") ? atoi(getenv("NERF_DENSITY_BLOCKS_PER_CU")) : 0;
     // two workgroups (eight waves) per CU measured best for both kernels: the density kernel could hold five, but runs
     // 0.307 ms at two against 0.325 ms at five and 0.341 ms with a grid of eight per CU (more waves only thrash the L2
     // with more random gathers in flight); NERF_FWD_BLOCKS_PER_CU / NERF_DENSITY_BLOCKS_PER_CU override for tuning
-    if (per_cu > 2) per_cu = 2;
+    // (pixel-ordered rays, NerfPointSrc.ray_block: the density pass gains from a third workgroup, 71.7 -> 69.3 ms per
+    // 800 x 800 image; the full field does not: 1 / 2 / 3 / 4 per CU = 89.6 / 71.7 / 77.4 / 72.9 ms)
+    const int most = (!color && coherent) ? 3 : 2;
+    if (per_cu > most) per_cu = most;
     if (color && forced > 0) per_cu = forced;
     if (!color && forced_d > 0) per_cu = forced_d;
     const int64_t cap = (int64_t)kNumCU * (per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu));
@@ -514,7 +517,7 @@ static int launch_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const floa
         if (e != hipSuccess) { nerf_set_error("field_fwd: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }  \
         static int per_cu = 0, per_cu_lds = -1;     /* per instantiation; the net shape rarely changes */              \
         if (per_cu_lds != lds_bytes) { per_cu = resident_blocks_per_cu(kern, threads, lds_bytes); per_cu_lds = lds_bytes; } \
-        const unsigned nb = fwd_grid(src->n_points, threads > 256 ? (per_cu > 1 ? 1 : per_cu) : per_cu, waves, COLOR);   \
+        const unsigned nb = fwd_grid(src->n_points, threads > 256 ? (per_cu > 1 ? 1 : per_cu) : per_cu, waves, COLOR, src->ray_block != 0);   \
         kern<<<nb, threads, lds_bytes, st>>>(g, s, table, sw, cw, latent, *src, sigma, rgb, xh, xyz, xh_in, stage_off); \
     } while (0)
     switch (grid->n_features) {
