@@ -433,7 +433,12 @@ class NeRFNetwork(nn.Module):
         if encoding_dir_degree not in (0, 2, 4) or latent_embedding_dim % 2 or not 0 <= latent_embedding_dim <= 48:
             raise NotImplementedError('fused kernels need SH degree 0, 2 or 4 and an even latent_embedding_dim <= 48')
         # precision: the reference's fp16 switch only changes tcnn's storage type; this build computes in
-        # fp32 (the CPU/fp32 semantics are the parity spec), so both values run fp32.
+        # fp32 (the CPU/fp32 semantics are the parity spec), so both values run fp32 -- said out loud
+        # once, not silently: a caller who asked for half precision gets MORE precision and an fp32-sized table.
+        if 'float16' in (encoding_precision, encoding_dir_precision if encoding_dir_degree != 0 else None):
+            import warnings
+            warnings.warn("nerf_amd: encoding_precision / encoding_dir_precision 'float16' runs in float32 (tables, "
+                          "activations and optimizer state are fp32 in this build)", stacklevel=2)
         self.encoding_precision = torch.float32
         sd = (lambda k: None if seed is None else seed + k)
         self.encoder = HashGridEncoding(encoding_n_levels, encoding_n_features_per_level, encoding_log2_hashmap_size,
