@@ -58,10 +58,18 @@ def algorithmic_bytes(name, n_rays, n_params, Sc=64, Sf=SF, L=20, F=2):
         'nerf_field_from_features': n_rays * Sf * (L * F * 4 + 4 + 12 + 12),
         'nerf_density_from_features': n_rays * Sc * (L * F * 4 + 4),
         'nerf_adam_step': None,                  # per-tensor launches: 32 B / parameter, summed below
+        # per-ray kernels: sigma in, fine depths (log and linear) out, + the noise array unless drawn in-kernel
         'nerf_coarse_to_fine': n_rays * (4 * Sc + 12 * Sf),
+        'nerf_coarse_to_fine_rng': n_rays * (4 * Sc + 8 * Sf),
+        # sigma 4 + rgb 12 + z 4 + zlog 4 read, weights 4 + zlog_s 4 written per sample; image + invdepth per ray
         'nerf_composite_fwd': n_rays * (Sf * 32 + 16),
-        'nerf_composite_bwd': n_rays * (Sf * 44 + 12),
+        # sigma 4 + rgb 12 + zlog 4 + dweights 4 read, dsigma 4 + drgb 12 written per sample; dimage per ray
+        'nerf_composite_bwd': n_rays * (Sf * 40 + 12),
         'nerf_losses': n_rays * (Sf * 12 + 36),
+        # the fused tail of the training step: compositing + losses (gt, image, invdepth per ray), and their backward
+        # (sigma, rgb, zlog read, dsigma, drgb written; gt + image per ray)
+        'nerf_composite_loss_fwd': n_rays * (Sf * 32 + 28),
+        'nerf_composite_loss_bwd': n_rays * (Sf * 36 + 24),
         'nerf_raygen': n_rays * (16 + 36 + 64 + 24),
     }.get(name)
 
@@ -143,9 +151,69 @@ def _cpu_steps(ora, R, opt, n_rays, steps, warm, seed):
             'adam_s': med([r[2] for r in rows]), 'rays_per_s': n_rays / tot, 'render_only_rays_per_s': n_rays / t_render}
 
 
-def cpu_baseline(n_rays=4096, steps=3, threads=16):
+def per_ray_kernels_at(n_rays=65536, Sc=64, Sf=SF, reps=20):
+    """The per-ray kernels (resampling, compositing, their fused training forms and backward passes) at a batch where
+    bandwidth, not launch latency, is what is measured: `n_rays` rays x (Sc coarse, Sf fine) of synthetic rows, every entry
+    point called through the C ABI `reps` times between two HIP events on the launch stream.  Returns a list of
+    {name, avg_launch_ms, algorithmic_bytes_per_launch, algorithmic_GBps, hbm_frac}."""
+    import ctypes as C
+    import math
+    from nerf_amd._lib import check, lib, ptr, stream
+    dev = 'cuda'
+    g = torch.Generator(device=dev).manual_seed(3)
+    N = n_rays
+    sig_c = torch.rand(N, Sc, device=dev, generator=g) * 20
+    zlog_c = torch.linspace(math.log10(1.6), math.log10(4.8), Sc + 1, device=dev)[:Sc].contiguous()
+    lin = torch.linspace(0, 1 - 1 / Sf, Sf).to(dev)
+    steps = (C.c_int32 * 1)(Sc)
+    zlog_f, z_f = torch.empty(N, Sf, device=dev), torch.empty(N, Sf, device=dev)
+    sig = torch.rand(N, Sf, device=dev, generator=g) * 20
+    rgb = torch.rand(N, Sf, 3, device=dev, generator=g)
+    bg, gt = torch.rand(3, device=dev, generator=g), torch.rand(N, 3, device=dev, generator=g)
+    image, invd = torch.empty(N, 3, device=dev), torch.empty(N, device=dev)
+    wts, zs = torch.empty(N, Sf, device=dev), torch.empty(N, Sf, device=dev)
+    dsig, drgb = torch.empty(N, Sf, device=dev), torch.empty(N, Sf, 3, device=dev)
+    dimg, dw = torch.rand(N, 3, device=dev, generator=g), torch.rand(N, Sf, device=dev, generator=g)
+    sums = torch.empty(8 + 4 * 1024, device=dev, dtype=torch.float64)
+    out6 = torch.empty(6, device=dev)
+    lo, rng = math.log10(1.6), math.log10(4.8) - math.log10(1.6)
+    L = lib()
+    calls = [
+        ('nerf_coarse_to_fine_rng', lambda: L.nerf_coarse_to_fine_rng(ptr(sig_c), ptr(zlog_c), 0, 1, 2, ptr(lin), N, Sc, Sf, 0.2,
+                                                                      steps, 1, ptr(zlog_f), ptr(z_f), stream())),
+        ('nerf_composite_fwd', lambda: L.nerf_composite_fwd(ptr(sig), ptr(rgb), ptr(z_f), ptr(zlog_f), ptr(bg), N, Sf, lo, rng,
+                                                            ptr(image), ptr(invd), ptr(wts), ptr(zs), stream())),
+        ('nerf_composite_bwd', lambda: L.nerf_composite_bwd(ptr(sig), ptr(rgb), ptr(zlog_f), ptr(bg), ptr(dimg), ptr(dw), N, Sf,
+                                                            ptr(dsig), ptr(drgb), stream())),
+        ('nerf_composite_loss_fwd', lambda: L.nerf_composite_loss_fwd(ptr(sig), ptr(rgb), ptr(z_f), ptr(zlog_f), ptr(bg), ptr(gt), N,
+                                                                      Sf, lo, rng, 1e-3, 1e-1, ptr(image), ptr(invd), ptr(wts),
+                                                                      ptr(zs), ptr(sums), ptr(out6), stream())),
+        ('nerf_composite_loss_bwd', lambda: L.nerf_composite_loss_bwd(ptr(sig), ptr(rgb), ptr(zlog_f), ptr(bg), ptr(gt), ptr(image),
+                                                                      None, N, Sf, lo, rng, 1e-3, 1e-1, ptr(dsig), ptr(drgb),
+                                                                      sums.data_ptr() + 40, stream())),
+    ]
+    rows = []
+    for name, fn in calls:
+        for _ in range(3):
+            check(fn(), name)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / reps
+        nbytes = algorithmic_bytes(name, N, 0, Sc=Sc, Sf=Sf)
+        rows.append({'name': name, 'rays': N, 'avg_launch_ms': round(ms, 4), 'algorithmic_bytes_per_launch': nbytes,
+                     'algorithmic_GBps': round(nbytes / (ms * 1e-3) / 1e9, 1),
+                     'hbm_frac': round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+    return rows
+
+
+def cpu_baseline(n_rays=4096, steps=10, warm=3, threads=16):
     """The CPU oracle (oracle/ref_cpu.py, fp32 torch CPU; a port -- the reference's network needs the CUDA-only tinycudann)
-    on a bounded sample of the SAME workload: `steps` timed train steps (after one warm-up) of `n_rays` rays of the
+    on a bounded sample of the SAME workload: `steps` timed train steps (after `warm` warm-up steps; BASELINE.md section 3:
+    3 + >= 10, median) of `n_rays` rays of the
     metric configuration, config_base network with the 2^24 table and torch.optim.Adam over all of it; then, for
     orientation, SURVEY's C1 case (1024 rays, 480 coarse + 128 fine samples).  Phases are reported separately: the dense
     Adam pass over 400 M parameters does not shrink with the batch."""
@@ -155,7 +223,7 @@ def cpu_baseline(n_rays=4096, steps=3, threads=16):
     ora = ref_cpu.OracleNetwork(N_IMAGES, seed=0, **NET)
     opt = ref_cpu.make_optimizer(ora)
     R = ref_cpu.OracleRenderer(ora, INNER, OUTER, Z_BOUNDS, STEPS, SF, ALPHA)
-    main = _cpu_steps(ora, R, opt, n_rays, steps, 1, 0)
+    main = _cpu_steps(ora, R, opt, n_rays, steps, warm, 0)
     R1 = ref_cpu.OracleRenderer(ora, INNER, OUTER, [0.1, 1, 10, 100, 1000], [256, 128, 64, 32], SF, ALPHA)
     c1 = _cpu_steps(ora, R1, opt, 1024, 2, 1, 1)
     cpu_model = ''
@@ -166,8 +234,8 @@ def cpu_baseline(n_rays=4096, steps=3, threads=16):
         pass
     return {'value': main['rays_per_s'], 'unit': 'rays/s', 'cores': threads, 'kind': 'port',
             'render_rays_per_s': main['render_only_rays_per_s'], 'cpu_model': cpu_model, 'host_cpus': os.cpu_count(),
-            'sample': '%d timed train steps of %d rays (1 warm-up, median), %d coarse + %d fine samples, oracle/ref_cpu.py fp32 '
-                      'torch CPU, same network / renderer / Adam configuration' % (steps, n_rays, sum(STEPS), SF),
+            'sample': '%d timed train steps of %d rays (%d warm-up, median), %d coarse + %d fine samples, oracle/ref_cpu.py fp32 '
+                      'torch CPU, same network / renderer / Adam configuration' % (steps, n_rays, warm, sum(STEPS), SF),
             'seconds_per_step': main['seconds_per_step'],
             'phases_s': {k: main[k] for k in ('render_fwd_s', 'loss_backward_s', 'adam_s')},
             'c1_1024_rays_480_coarse': {k: c1[k] for k in ('rays_per_s', 'render_only_rays_per_s', 'seconds_per_step',
@@ -459,6 +527,10 @@ def main():
         render['rays_per_s_chunks_16384'] = H * W / (time.perf_counter() - t2)
         _beat()
 
+    # the per-ray kernels at 65 536 rays: their bandwidth is invisible at 4096 rays (launch-latency-bound there)
+    per_ray = per_ray_kernels_at(65536, Sc=sum(STEPS)) if (rank == 0 and world == 1 and not args.no_render) else None
+    _beat()
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         del model, renderer, loader, opt
@@ -479,7 +551,8 @@ def main():
                                       ('level_sharded' if getattr(model_sharded, 'world', 1) > 1 else 'replicated_fallback')),
                        'parallelism': ('dp%d over rays' % world) + (', hash table sharded by level (feature all-to-all)'
                                                                     if getattr(model_sharded, 'world', 1) > 1 else '') + fallback_note},
-            'roofline': roofline, 'roofline_second': roofline_2, 'cpu_baseline': cpu, 'render': render, 'kernels': kernels,
+            'roofline': roofline, 'roofline_second': roofline_2, 'cpu_baseline': cpu, 'render': render,
+            'per_ray_kernels_65536_rays': per_ray, 'kernels': kernels,
         }
     if world > 1:
         dist.barrier()       # every rank got here: only now may rank 0 report

@@ -26,10 +26,10 @@
 extern "C" {
 #endif
 
-#define NERF_ABI_VERSION 2
+#define NERF_ABI_VERSION 3
 #define NERF_MAX_LEVELS 32
 #define NERF_MAX_SEGMENTS 16
-#define NERF_MAX_SAMPLES 512 /* per-ray kernels keep one ray in LDS */
+#define NERF_MAX_SAMPLES 512 /* per-ray kernels: one wavefront per ray, at most 8 samples per lane */
 
 #define NERF_EINVAL (-1)   /* null pointer / bad size */
 #define NERF_EUNSUPPORTED (-2) /* configuration outside what the fused kernels cover */
@@ -280,9 +280,13 @@ int nerf_composite_loss_fwd(const float* sigma, const float* rgb, const float* z
                             float lam_dist, float lam_depth, float* image, float* invdepth, float* weights,
                             float* zlog_s /*nullable*/, double* sums /*[NERF_LOSS_SUMS_DOUBLES]*/, float* loss_out /*[6]*/,
                             void* stream);
+/* nonfinite_flag (nullable): the step's flag, sums + 5 of the forward call.  The backward sets it to 1 when a gradient it
+ * writes is NaN / Inf although the loss was finite (an Inf upstream gradient, an overflow): GradScaler.step skips on
+ * non-finite GRADIENTS (trainer.py:134-136), and the guarded optimizer entry points read the flag after this kernel. */
 int nerf_composite_loss_bwd(const float* sigma, const float* rgb, const float* zlog, const float* bg, const float* gt,
                             const float* image, const float* dout, int64_t n_rays, int n_samples, float zlog_lo,
-                            float zlog_range, float lam_dist, float lam_depth, float* dsigma, float* drgb, void* stream);
+                            float zlog_range, float lam_dist, float lam_depth, float* dsigma, float* drgb,
+                            double* nonfinite_flag, void* stream);
 
 /* ---- optimizer: torch.optim.Adam as configured at train.py:84-88 (dense, L2 weight decay) ---- */
 /* step is the 1-based step count; when zero_grad != 0 the gradient is cleared in the same pass. */

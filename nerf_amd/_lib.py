@@ -87,7 +87,7 @@ SIGNATURES = {
     'nerf_composite_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I64, _I, _P, _P, _P]),
     'nerf_losses': (_I, [_P, _P, _P, _P, _I64, _I, _F, _F, _F, _I, _P, _P, _P, _P]),
     'nerf_composite_loss_fwd': (_I, [_P, _P, _P, _P, _P, _P, _I64, _I, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
-    'nerf_composite_loss_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, _I, _F, _F, _F, _F, _P, _P, _P]),
+    'nerf_composite_loss_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, _I, _F, _F, _F, _F, _P, _P, _P, _P]),
     'nerf_adam_step': (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _I64, _F, _I, _P]),
     'nerf_adam_step_guarded': (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _I64, _F, _I, _P, _P]),
     'nerf_table_update_binned_guarded': (_I, [_G, _LS, _I64, _P, _I64, _P, _P, _P, _F, _F, _F, _F, _F, _I64, _F, _P, _P]),
@@ -173,7 +173,7 @@ def lib():
             fn.argtypes = args
             launches = res is _I and name not in ('nerf_abi_version',)
             setattr(l, name, _Timed(name, fn) if launches else fn)
-        if l.nerf_abi_version() != 2:
+        if l.nerf_abi_version() != 3:
             raise RuntimeError('libnerf_hip.so ABI version mismatch')
         _lib = l
     return _lib

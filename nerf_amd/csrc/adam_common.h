@@ -15,6 +15,10 @@ struct AdamK {
 __device__ __forceinline__ void adam1(float& p, float& g, float& m, float& v, const AdamK& k) {
     float gr = g * k.gscale;
     if (k.wd != 0.f) gr = fmaf(k.wd, p, gr);
+    // A NaN / Inf gradient must never reach p, m, v (it would stay in the moments for good): the entry keeps its state.
+    // The whole-step guard (skip flag: non-finite loss, non-finite compositing gradients) is GradScaler's rule
+    // (trainer.py:134-136); this is the safety net under it for anything that overflows further down the backward pass.
+    if (!(fabsf(gr) <= 3.402823466e38f)) return;
     m = m + k.one_m_beta1 * (gr - m);                 // exp_avg.lerp_(grad, 1 - beta1)
     v = fmaf(k.one_m_beta2 * gr, gr, v * k.beta2);    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
     const float denom = sqrtf(v) * k.inv_sqrt_bc2 + k.eps;

@@ -108,8 +108,8 @@ extern "C" int nerf_density_bwd_input(const NerfGridCfg* grid, const NerfNetCfg*
 #define LAUNCH(FF)                                                                                                       \
     do {                                                                                                                 \
         auto kern = density_dx_kernel<FF>;                                                                               \
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);    \
-        if (e != hipSuccess) { nerf_set_error("density_bwd_input: LDS attribute: %s", hipGetErrorString(e)); return (int)e; } \
+        static NerfLdsAttrCache lds_cache = {};   /* per instantiation */    \
+        if (int e = nerf_ensure_dynamic_lds((const void*)kern, lds_bytes, &lds_cache, "density_bwd_input")) return e;    \
         kern<<<nb, 256, lds_bytes, st>>>(g, table, sigma_params, *src, dsigma, dx);                                      \
     } while (0)
     switch (grid->n_features) {

@@ -429,8 +429,8 @@ extern "C" int nerf_field_bwd(const NerfGridCfg* grid, const NerfNetCfg* net, co
 #define LAUNCH3(FF, XX, RR)                                                                                            \
     do {                                                                                                               \
         auto kern = field_bwd_kernel<FF, XX, RR>;                                                                        \
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);  \
-        if (e != hipSuccess) { nerf_set_error("field_bwd: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }  \
+        static NerfLdsAttrCache lds_cache = {};   /* per instantiation */    \
+        if (int e = nerf_ensure_dynamic_lds((const void*)kern, lds_bytes, &lds_cache, "field_bwd")) return e;    \
         kern<<<nb, 256, lds_bytes, st>>>(g, s, sigma_params, color_params, latent_emb, *src, x_hashtable, dsigma, drgb, \
                                          dfeat, dsigma_params, dcolor_params, dlatent, sb_rows);                       \
     } while (0)

@@ -513,8 +513,8 @@ static int launch_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const floa
 #define LAUNCH(FF)                                                                                                     \
     do {                                                                                                               \
         auto kern = field_fwd_kernel<FF, COLOR, FEATS>;                                                                     \
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);  \
-        if (e != hipSuccess) { nerf_set_error("field_fwd: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }  \
+        static NerfLdsAttrCache lds_cache = {};   /* per instantiation */    \
+        if (int e = nerf_ensure_dynamic_lds((const void*)kern, lds_bytes, &lds_cache, "field_fwd")) return e;    \
         static int per_cu = 0, per_cu_lds = -1;     /* per instantiation; the net shape rarely changes */              \
         if (per_cu_lds != lds_bytes) { per_cu = resident_blocks_per_cu(kern, threads, lds_bytes); per_cu_lds = lds_bytes; } \
         const unsigned nb = fwd_grid(src->n_points, threads > 256 ? (per_cu > 1 ? 1 : per_cu) : per_cu, waves, COLOR, src->ray_block != 0);   \
@@ -618,8 +618,8 @@ static int launch_scatter(const NerfGridCfg* grid, const NerfPointSrc* src, cons
 #define LAUNCH_SMALL(FF)                                                                                                  \
         do {                                                                                                              \
             auto kern = scatter_small_kernel<FF>;                                                                         \
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
-            if (e != hipSuccess) { nerf_set_error("scatter: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }   \
+            static NerfLdsAttrCache lds_cache = {};   /* per instantiation */    \
+            if (int e = nerf_ensure_dynamic_lds((const void*)kern, lds_bytes, &lds_cache, "scatter")) return e;    \
             kern<<<nb, kSmallThreads, lds_bytes, st>>>(g, s, x01, dfeat, n_points, dtable, ss, stride);                   \
         } while (0)
         switch (F) {

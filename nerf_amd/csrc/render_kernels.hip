@@ -3,7 +3,8 @@
 // compositing (forward + backward) and the fused training losses.
 //
 // All of them are HBM-bandwidth-bound streaming kernels: one 64-lane wavefront owns one ray,
-// rows are staged through LDS with coalesced loads, and the along-ray recurrences
+// a row goes from HBM straight into the registers of the lanes that own its samples (coalesced
+// 8 / 16-byte pieces, no LDS staging, no workgroup barriers), and the along-ray recurrences
 // (transmittance product, CDF sum, suffix sums) are wavefront prefix scans carried in fp64 and
 // rounded to fp32 per element -- exactly how the reference's CPU cumsum/cumprod behave
 // (SURVEY.md F6), which is what makes the resampled indices bit-exact.
@@ -13,6 +14,8 @@
 #pragma clang fp contract(off)
 
 #include <stdlib.h>
+#include <initializer_list>
+#include <type_traits>
 #include "common.h"
 #include "philox.h"
 
@@ -20,7 +23,6 @@ namespace {
 
 constexpr int kRaysPerBlock = 4;  // 256 threads, one wavefront per ray
 constexpr int kMaxS = NERF_MAX_SAMPLES;
-constexpr int kMaxC = kMaxS / kWave;  // samples per lane, contiguous
 
 // ------------------------------------------------------------------------------------------
 // wavefront scans (fp64)
@@ -63,10 +65,6 @@ __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
     return v;
-}
-
-__device__ __forceinline__ void load_row(float* dst, const float* src, int n, int lane) {
-    for (int i = lane; i < n; i += kWave) dst[i] = src[i];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -154,54 +152,123 @@ __global__ void contract_kernel(const float* __restrict__ xyz, int64_t n, float 
 }
 
 // ------------------------------------------------------------------------------------------
-// Per-ray stages on LDS rows.  Lane `lane` owns the contiguous samples [lane*C, lane*C + C).
+// Per-ray kernels.  One wavefront owns one ray; lane `lane` owns the C contiguous samples [lane*C, lane*C + C) of the
+// ray's rows, C = 1, 2, 4 or 8 (the smallest with 64*C >= S, a template parameter: no code for samples a launch does
+// not have).  A row goes from HBM straight into the registers of the lanes that own it, as 4 / 8 / 16-byte pieces of
+// one contiguous run per wave instruction (VEC: S a multiple of W = min(C, 4) and every row base 4W-byte aligned;
+// else 4-byte pieces), neighbours across a lane boundary come from DPP shuffles, results leave the same way.  Only the
+// resampling stage needs random access to a row (the CDF search): it keeps two rows per ray in LDS, sized by the
+// launch's S.  The waves of a workgroup share nothing, so there are no workgroup barriers and a dead tail wave exits.
 // ------------------------------------------------------------------------------------------
+typedef float vf2 __attribute__((ext_vector_type(2)));
+typedef float vf4 __attribute__((ext_vector_type(4)));
+
+template <int C> struct VecW { static constexpr int W = C < 4 ? C : 4; };
+
+// v[0..N) = row[first .. first + N) where the index is below `limit`, else 0
+template <int N, bool VEC, int W>
+__device__ __forceinline__ void load_run(float (&v)[N], const float* __restrict__ row, int first, int limit) {
+    if constexpr (VEC && W == 4) {
+#pragma unroll
+        for (int j = 0; j < N; j += 4) {
+            vf4 t = {0.f, 0.f, 0.f, 0.f};
+            if (first + j < limit) t = *(const vf4*)(row + first + j);
+            v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w;
+        }
+    } else if constexpr (VEC && W == 2) {
+#pragma unroll
+        for (int j = 0; j < N; j += 2) {
+            vf2 t = {0.f, 0.f};
+            if (first + j < limit) t = *(const vf2*)(row + first + j);
+            v[j] = t.x; v[j + 1] = t.y;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = first + j < limit ? row[first + j] : 0.f;
+    }
+}
+
+template <int N, bool VEC, int W>
+__device__ __forceinline__ void store_run(float* __restrict__ row, const float (&v)[N], int first, int limit) {
+    if constexpr (VEC && W == 4) {
+#pragma unroll
+        for (int j = 0; j < N; j += 4)
+            if (first + j < limit) { vf4 t = {v[j], v[j + 1], v[j + 2], v[j + 3]}; *(vf4*)(row + first + j) = t; }
+    } else if constexpr (VEC && W == 2) {
+#pragma unroll
+        for (int j = 0; j < N; j += 2)
+            if (first + j < limit) { vf2 t = {v[j], v[j + 1]}; *(vf2*)(row + first + j) = t; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+            if (first + j < limit) row[first + j] = v[j];
+    }
+}
+
+// LDS traffic of ONE wave: its own earlier writes are visible to all its lanes once the compiler keeps the order
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 struct SegCfg {
     int n_seg;
     int start[NERF_MAX_SEGMENTS + 1];
     float scale[NERF_MAX_SEGMENTS];
 };
 
-// R6 (renderer.py:154-160): sig[S], zl[S] in LDS -> wpad[0..S+1] in LDS (zero padded both ends).
-__device__ __forceinline__ void stage_weights(const float* sig, const float* zl, float* wpad, int S, int C, int lane) {
-    float alpha[kMaxC];
-    double om_local[kMaxC];
+// renderer.py:73-79 / :154-160: alpha_i = 1 - exp(-sigma_i delta_i), T_i = prod_{j<i}(1 - alpha_j) (fp64 product, as the
+// CPU cumprod accumulates), w_i = alpha_i T_i.  delta in log10 depth, 0 for the last sample.
+template <int C>
+struct Trans {
+    float alpha[C], delta[C], wgt[C];
+    double om_local[C];     // product of (1 - alpha) over the chunk's earlier samples
+    double before;          // ... over the samples of all earlier lanes
+};
+
+template <int C>
+__device__ __forceinline__ void transmittance(Trans<C>& t, const float (&sig)[C], const float (&zl)[C], int S, int lane) {
+    const float zl_next_lane = __shfl_down(zl[0], 1, kWave);
     double prod = 1.0;
 #pragma unroll
-    for (int c = 0; c < kMaxC; ++c) {
-        int i = lane * C + c;
-        alpha[c] = 0.f;
-        om_local[c] = prod;
-        if (c < C && i < S) {
-            float delta = (i < S - 1) ? (zl[i + 1] - zl[i]) : 0.f;
-            float a = 1.f - expf(-sig[i] * delta);
-            alpha[c] = a;
+    for (int c = 0; c < C; ++c) {
+        const int i = lane * C + c;
+        t.alpha[c] = 0.f;
+        t.delta[c] = 0.f;
+        t.om_local[c] = prod;
+        if (i < S) {
+            const float zn = c + 1 < C ? zl[c + 1 < C ? c + 1 : c] : zl_next_lane;
+            const float d = (i < S - 1) ? (zn - zl[c]) : 0.f;
+            const float a = 1.f - expf(-sig[c] * d);
+            t.alpha[c] = a;
+            t.delta[c] = d;
             prod *= (double)(1.f - a);
         }
     }
-    double before = wave_excl_prod(prod, lane);
+    t.before = wave_excl_prod(prod, lane);
 #pragma unroll
-    for (int c = 0; c < kMaxC; ++c) {
-        int i = lane * C + c;
-        if (c < C && i < S) wpad[i + 1] = alpha[c] * (float)(before * om_local[c]);
-    }
-    if (lane == 0) {
-        wpad[0] = 0.f;
-        wpad[S + 1] = 0.f;
-    }
+    for (int c = 0; c < C; ++c) t.wgt[c] = (lane * C + c < S) ? t.alpha[c] * (float)(t.before * t.om_local[c]) : 0.f;
 }
 
-// R7 (renderer.py:132-142): wpad -> pdf[S]
-__device__ __forceinline__ void stage_reweight(const float* wpad, float* pdf, int S, int C, int lane, float alpha_over_s,
+// R7 (renderer.py:132-142): w[C] -> pdf[C]
+template <int C>
+__device__ __forceinline__ void stage_reweight(const float (&w)[C], float (&pdf)[C], int S, int lane, float alpha_over_s,
                                                const SegCfg& seg) {
-    float v[kMaxC];
+    float w_prev_lane = __shfl_up(w[C - 1], 1, kWave);
+    if (lane == 0) w_prev_lane = 0.f;                           // the zero padding of :133
+    const float w_next_lane = __shfl_down(w[0], 1, kWave);
+    float v[C];
     double local = 0.0;
 #pragma unroll
-    for (int c = 0; c < kMaxC; ++c) {
-        int i = lane * C + c;
+    for (int c = 0; c < C; ++c) {
+        const int i = lane * C + c;
         v[c] = 0.f;
-        if (c < C && i < S) {
-            float x = 0.5f * (fmaxf(wpad[i], wpad[i + 1]) + fmaxf(wpad[i + 1], wpad[i + 2]));
+        if (i < S) {
+            const float prev = c > 0 ? w[c > 0 ? c - 1 : 0] : w_prev_lane;
+            float next = c + 1 < C ? w[c + 1 < C ? c + 1 : c] : w_next_lane;
+            if (i + 1 >= S) next = 0.f;
+            float x = 0.5f * (fmaxf(prev, w[c]) + fmaxf(w[c], next));
             x = x + alpha_over_s;
             float sc = 1.f;
             for (int k = 0; k < seg.n_seg; ++k)
@@ -211,37 +278,29 @@ __device__ __forceinline__ void stage_reweight(const float* wpad, float* pdf, in
             local += (double)x;
         }
     }
-    float total = (float)wave_sum(local);
+    const float total = (float)wave_sum(local);
 #pragma unroll
-    for (int c = 0; c < kMaxC; ++c) {
-        int i = lane * C + c;
-        if (c < C && i < S) pdf[i] = v[c] / total;
-    }
+    for (int c = 0; c < C; ++c) pdf[c] = (lane * C + c < S) ? v[c] / total : 0.f;
 }
 
-// R8 (renderer.py:87-118, :165): pdf[S] (LDS, overwritten by the cdf), zl[S] -> fine depths
-template <class NoiseFn>
-__device__ __forceinline__ void stage_sample_pdf(float* pdf_cdf, const float* zl, int S, int C, int lane,
-                                                 NoiseFn noise, const float* __restrict__ lin, int Sf,
+// R8 (renderer.py:87-118, :165): pdf[C], zl[C] -> fine depths.  cdf_s / zl_s: this wave's two LDS rows of S floats.
+template <int C, class NoiseFn>
+__device__ __forceinline__ void stage_sample_pdf(const float (&pdf)[C], const float (&zl)[C], float* cdf_s, float* zl_s, int S,
+                                                 int lane, NoiseFn noise, const float* __restrict__ lin, int Sf,
                                                  float* __restrict__ zlog_f, float* __restrict__ z_f,
-                                                 int64_t* __restrict__ inds, bool live) {
-    float p[kMaxC];
+                                                 int64_t* __restrict__ inds) {
     double local = 0.0;
 #pragma unroll
-    for (int c = 0; c < kMaxC; ++c) {
-        int i = lane * C + c;
-        p[c] = (c < C && i < S) ? pdf_cdf[i] : 0.f;
-        local += (double)p[c];
-    }
+    for (int c = 0; c < C; ++c) local += (double)pdf[c];
     double run = wave_excl_sum(local, lane);
 #pragma unroll
-    for (int c = 0; c < kMaxC; ++c) {
-        int i = lane * C + c;
-        run += (double)p[c];
-        if (c < C && i < S) pdf_cdf[i] = (float)run;
+    for (int c = 0; c < C; ++c) {
+        const int i = lane * C + c;
+        run += (double)pdf[c];
+        if (i < S) { cdf_s[i] = (float)run; zl_s[i] = zl[c]; }
     }
-    __syncthreads();
-    const float* cdf = pdf_cdf;
+    wave_lds_sync();
+    const float* cdf = cdf_s;
     const float c1 = cdf[1], range = cdf[S - 2] - c1, fSf = (float)Sf;
     const int n_knots = S - 3;  // cdf[1 .. S-3]
     for (int k = lane; k < Sf; k += kWave) {
@@ -256,9 +315,8 @@ __device__ __forceinline__ void stage_sample_pdf(float* pdf_cdf, const float* zl
         int idx = lo + 1;
         float below = cdf[idx - 1], above = cdf[idx];
         float t = (u - below) / (above - below);
-        float mb = (zl[idx - 1] + zl[idx]) / 2.f, ma = (zl[idx] + zl[idx + 1]) / 2.f;
+        float mb = (zl_s[idx - 1] + zl_s[idx]) / 2.f, ma = (zl_s[idx] + zl_s[idx + 1]) / 2.f;
         float zf = mb + (ma - mb) * t;
-        if (!live) continue;
         zlog_f[k] = zf;
         if (z_f) z_f[k] = powf(10.f, zf);
         if (inds) inds[k] = idx;
@@ -266,124 +324,94 @@ __device__ __forceinline__ void stage_sample_pdf(float* pdf_cdf, const float* zl
 }
 
 // mode 0: sigma -> weights ; 1: weights -> pdf ; 2: pdf -> fine ; 3: sigma -> fine (fused)
-template <int MODE>
+template <int MODE, int C, bool VEC>
 __global__ __launch_bounds__(256) void ray_sampling_kernel(const float* __restrict__ in, const float* __restrict__ zlog,
                                                            int64_t zlog_stride, const float* __restrict__ noise,
                                                            const float* __restrict__ lin, int64_t n_rays, int S, int Sf,
                                                            float alpha_over_s, SegCfg seg, float* __restrict__ out_a,
                                                            float* __restrict__ out_b, int64_t* __restrict__ inds,
                                                            uint64_t seed, uint64_t counter) {
-    __shared__ float s_w[kRaysPerBlock][kMaxS + 2];
-    __shared__ float s_p[kRaysPerBlock][kMaxS];
-    __shared__ float s_z[kRaysPerBlock][kMaxS];
+    extern __shared__ float s_rows[];       // MODE 2 / 3: [kRaysPerBlock][2][S]
+    constexpr int W = VecW<C>::W;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wv;
-    const bool live = ray < n_rays;
-    if (!live) ray = n_rays - 1;  // keep every wave on the barriers; stores are masked below
-    const int C = (S + kWave - 1) / kWave;
-    float* wpad = s_w[wv];
-    float* pp = s_p[wv];
-    float* zl = s_z[wv];
-    if (MODE != 1) load_row(zl, zlog + ray * zlog_stride, S, lane);
-    if (MODE == 0 || MODE == 3) load_row(pp, in + ray * S, S, lane);  // sigma
-    if (MODE == 1) {
-        load_row(wpad + 1, in + ray * S, S, lane);
-        if (lane == 0) { wpad[0] = 0.f; wpad[S + 1] = 0.f; }
-    }
-    if (MODE == 2) load_row(pp, in + ray * S, S, lane);  // pdf
-    __syncthreads();
+    const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wv;
+    if (ray >= n_rays) return;
+    float a[C], zl[C], w[C], pdf[C];
+    load_run<C, VEC, W>(a, in + ray * S, lane * C, S);              // sigma (0, 3) / weights (1) / pdf (2)
+    if (MODE != 1) load_run<C, VEC, W>(zl, zlog + ray * zlog_stride, lane * C, S);
     if (MODE == 0 || MODE == 3) {
-        stage_weights(pp, zl, wpad, S, C, lane);
-        __syncthreads();
-        if (MODE == 0) {
-            if (live) for (int i = lane; i < S; i += kWave) out_a[ray * S + i] = wpad[i + 1];
-            return;
-        }
+        Trans<C> t;
+        transmittance(t, a, zl, S, lane);
+#pragma unroll
+        for (int c = 0; c < C; ++c) w[c] = t.wgt[c];
+        if (MODE == 0) { store_run<C, VEC, W>(out_a + ray * S, w, lane * C, S); return; }
+    }
+    if (MODE == 1) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) w[c] = a[c];
     }
     if (MODE == 1 || MODE == 3) {
-        stage_reweight(wpad, pp, S, C, lane, alpha_over_s, seg);
-        __syncthreads();
-        if (MODE == 1) {
-            if (live) for (int i = lane; i < S; i += kWave) out_a[ray * S + i] = pp[i];
-            return;
-        }
+        stage_reweight<C>(w, pdf, S, lane, alpha_over_s, seg);
+        if (MODE == 1) { store_run<C, VEC, W>(out_a + ray * S, pdf, lane * C, S); return; }
     }
-    // MODE 2 / 3.  Dead waves (tail block) run the stage on a clamped ray with stores masked.
+    if (MODE == 2) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) pdf[c] = a[c];
+    }
     // stratification noise (torch.rand of renderer.py:102): the caller's array, or element ray * Sf + k of the Philox stream
     // (seed, counter) -- the same numbers nerf_uniform_noise writes out
+    float* cdf_s = s_rows + (size_t)wv * 2 * S;
+    float* zl_s = cdf_s + S;
     if (noise) {
         const float* nz = noise + ray * Sf;
-        stage_sample_pdf(pp, zl, S, C, lane, [&](int k) { return nz[k]; }, lin, Sf, out_a + ray * Sf,
-                         out_b ? out_b + ray * Sf : nullptr, inds ? inds + ray * Sf : nullptr, live);
+        stage_sample_pdf<C>(pdf, zl, cdf_s, zl_s, S, lane, [&](int k) { return nz[k]; }, lin, Sf, out_a + ray * Sf,
+                            out_b ? out_b + ray * Sf : nullptr, inds ? inds + ray * Sf : nullptr);
     } else {
         const uint64_t e0 = (uint64_t)ray * (uint64_t)Sf;
-        stage_sample_pdf(pp, zl, S, C, lane, [&](int k) { return philox_uniform(seed, counter, e0 + (uint64_t)k); }, lin, Sf,
-                         out_a + ray * Sf, out_b ? out_b + ray * Sf : nullptr, inds ? inds + ray * Sf : nullptr, live);
+        stage_sample_pdf<C>(pdf, zl, cdf_s, zl_s, S, lane, [&](int k) { return philox_uniform(seed, counter, e0 + (uint64_t)k); },
+                            lin, Sf, out_a + ray * Sf, out_b ? out_b + ray * Sf : nullptr, inds ? inds + ray * Sf : nullptr);
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// R10: alpha compositing (renderer.py:71-85, 181-182), one wavefront per ray.
+// R10: alpha compositing (renderer.py:71-85, 181-182).
 // ------------------------------------------------------------------------------------------
+template <int C, bool VEC>
 __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restrict__ sigma, const float* __restrict__ rgb,
                                                             const float* __restrict__ z, const float* __restrict__ zlog,
                                                             const float* __restrict__ bg, int64_t n_rays, int S,
                                                             float zlog_lo, float zlog_range, float* __restrict__ image,
                                                             float* __restrict__ invdepth, float* __restrict__ weights,
                                                             float* __restrict__ zlog_s) {
-    __shared__ float s_sig[kRaysPerBlock][kMaxS];
-    __shared__ float s_zl[kRaysPerBlock][kMaxS];
-    __shared__ float s_z[kRaysPerBlock][kMaxS];
-    __shared__ float s_rgb[kRaysPerBlock][kMaxS * 3];
+    constexpr int W = VecW<C>::W;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wv;
-    const bool live = ray < n_rays;
-    if (!live) ray = n_rays - 1;
-    const int C = (S + kWave - 1) / kWave;
-    load_row(s_sig[wv], sigma + ray * S, S, lane);
-    load_row(s_zl[wv], zlog + ray * S, S, lane);
-    load_row(s_z[wv], z + ray * S, S, lane);
-    load_row(s_rgb[wv], rgb + ray * S * 3, S * 3, lane);
-    __syncthreads();
-    const float *sig = s_sig[wv], *zl = s_zl[wv], *zz = s_z[wv], *col = s_rgb[wv];
-    float alpha[kMaxC];
-    double om_local[kMaxC];
-    double prod = 1.0;
-#pragma unroll
-    for (int c = 0; c < kMaxC; ++c) {
-        int i = lane * C + c;
-        alpha[c] = 0.f;
-        om_local[c] = prod;
-        if (c < C && i < S) {
-            float delta = (i < S - 1) ? (zl[i + 1] - zl[i]) : 0.f;
-            float a = 1.f - expf(-sig[i] * delta);
-            alpha[c] = a;
-            prod *= (double)(1.f - a);
-        }
-    }
-    double before = wave_excl_prod(prod, lane);
+    const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wv;
+    if (ray >= n_rays) return;
+    float sig[C], zl[C], zz[C], col[3 * C];
+    load_run<C, VEC, W>(sig, sigma + ray * S, lane * C, S);
+    load_run<C, VEC, W>(zl, zlog + ray * S, lane * C, S);
+    load_run<C, VEC, W>(zz, z + ray * S, lane * C, S);
+    load_run<3 * C, VEC, W>(col, rgb + ray * S * 3, lane * 3 * C, 3 * S);
+    Trans<C> t;
+    transmittance(t, sig, zl, S, lane);
     double ar = 0, ag = 0, ab = 0, ainv = 0, aw = 0;
-    float* wrow = s_sig[wv];  // reuse: each lane overwrites only its own chunk
+    float ss[C];
 #pragma unroll
-    for (int c = 0; c < kMaxC; ++c) {
-        int i = lane * C + c;
-        if (c < C && i < S) {
-            float wgt = alpha[c] * (float)(before * om_local[c]);
-            ar += (double)(wgt * col[i * 3]);
-            ag += (double)(wgt * col[i * 3 + 1]);
-            ab += (double)(wgt * col[i * 3 + 2]);
-            ainv += (double)(wgt / zz[i]);
+    for (int c = 0; c < C; ++c) {
+        ss[c] = 0.f;
+        if (lane * C + c < S) {
+            const float wgt = t.wgt[c];
+            ar += (double)(wgt * col[c * 3]);
+            ag += (double)(wgt * col[c * 3 + 1]);
+            ab += (double)(wgt * col[c * 3 + 2]);
+            ainv += (double)(wgt / zz[c]);
             aw += (double)wgt;
-            wrow[i] = wgt;
+            ss[c] = (zl[c] - zlog_lo) / zlog_range;
         }
     }
     ar = wave_sum(ar); ag = wave_sum(ag); ab = wave_sum(ab); ainv = wave_sum(ainv); aw = wave_sum(aw);
-    __syncthreads();
-    if (!live) return;
-    for (int i = lane; i < S; i += kWave) {
-        weights[ray * S + i] = wrow[i];
-        if (zlog_s) zlog_s[ray * S + i] = (zl[i] - zlog_lo) / zlog_range;
-    }
+    store_run<C, VEC, W>(weights + ray * S, t.wgt, lane * C, S);
+    if (zlog_s) store_run<C, VEC, W>(zlog_s + ray * S, ss, lane * C, S);
     if (lane == 0) {
         float rest = 1.f - (float)aw;
         image[ray * 3] = (float)ar + rest * bg[0];
@@ -397,186 +425,110 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restr
 //   g_i       = dL/dw_i + dL/dimage . (c_i - bg)
 //   dL/dsig_i = delta_i * ( g_i T_{i+1} - sum_{k>i} g_k w_k )
 //   dL/dc_i   = w_i * dL/dimage
+// g[C] in, ds[C] / dc[3C] out; returns true when a gradient of this lane is not finite
+template <int C>
+__device__ __forceinline__ bool composite_grads(const Trans<C>& t, const float (&g)[C], float gi0, float gi1, float gi2, int S,
+                                                int lane, float (&ds)[C], float (&dc)[3 * C]) {
+    double gw_local = 0.0;
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+        if (lane * C + c < S) gw_local += (double)g[c] * (double)t.wgt[c];
+    const double after = wave_excl_suffix_sum(gw_local, lane);  // sum over lanes above
+    double suffix = after;                                      // walk the chunk from its last sample down
+    bool bad = false;
+#pragma unroll
+    for (int c = C - 1; c >= 0; --c) {
+        ds[c] = 0.f;
+        if (lane * C + c < S) {
+            const double t_next = t.before * t.om_local[c] * (double)(1.f - t.alpha[c]);
+            ds[c] = t.delta[c] * (float)((double)g[c] * t_next - suffix);
+            suffix += (double)g[c] * (double)t.wgt[c];
+        }
+        dc[c * 3] = t.wgt[c] * gi0;
+        dc[c * 3 + 1] = t.wgt[c] * gi1;
+        dc[c * 3 + 2] = t.wgt[c] * gi2;
+        bad |= !(fabsf(ds[c]) <= 3.402823466e38f) || !(fabsf(dc[c * 3]) <= 3.402823466e38f) ||
+               !(fabsf(dc[c * 3 + 1]) <= 3.402823466e38f) || !(fabsf(dc[c * 3 + 2]) <= 3.402823466e38f);
+    }
+    return bad;
+}
+
+template <int C, bool VEC>
 __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restrict__ sigma, const float* __restrict__ rgb,
                                                             const float* __restrict__ zlog, const float* __restrict__ bg,
                                                             const float* __restrict__ dimage,
                                                             const float* __restrict__ dweights, int64_t n_rays, int S,
                                                             float* __restrict__ dsigma, float* __restrict__ drgb) {
-    __shared__ float s_sig[kRaysPerBlock][kMaxS];
-    __shared__ float s_zl[kRaysPerBlock][kMaxS];
-    __shared__ float s_dw[kRaysPerBlock][kMaxS];
-    __shared__ float s_rgb[kRaysPerBlock][kMaxS * 3];
+    constexpr int W = VecW<C>::W;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wv;
-    const bool live = ray < n_rays;
-    if (!live) ray = n_rays - 1;
-    const int C = (S + kWave - 1) / kWave;
-    load_row(s_sig[wv], sigma + ray * S, S, lane);
-    load_row(s_zl[wv], zlog + ray * S, S, lane);
-    if (dweights) load_row(s_dw[wv], dweights + ray * S, S, lane);
-    else for (int i = lane; i < S; i += kWave) s_dw[wv][i] = 0.f;
-    load_row(s_rgb[wv], rgb + ray * S * 3, S * 3, lane);
-    __syncthreads();
-    const float *sig = s_sig[wv], *zl = s_zl[wv], *dw = s_dw[wv];
-    float* col = s_rgb[wv];
+    const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wv;
+    if (ray >= n_rays) return;
+    float sig[C], zl[C], dw[C], col[3 * C];
+    load_run<C, VEC, W>(sig, sigma + ray * S, lane * C, S);
+    load_run<C, VEC, W>(zl, zlog + ray * S, lane * C, S);
+    load_run<3 * C, VEC, W>(col, rgb + ray * S * 3, lane * 3 * C, 3 * S);
+    if (dweights) load_run<C, VEC, W>(dw, dweights + ray * S, lane * C, S);
+    else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) dw[c] = 0.f;
+    }
     const float gi0 = dimage[ray * 3], gi1 = dimage[ray * 3 + 1], gi2 = dimage[ray * 3 + 2];
     const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
-    float alpha[kMaxC], delta[kMaxC];
-    double om_local[kMaxC];
-    double prod = 1.0;
+    Trans<C> t;
+    transmittance(t, sig, zl, S, lane);
+    float g[C], ds[C], dc[3 * C];
 #pragma unroll
-    for (int c = 0; c < kMaxC; ++c) {
-        int i = lane * C + c;
-        alpha[c] = 0.f;
-        delta[c] = 0.f;
-        om_local[c] = prod;
-        if (c < C && i < S) {
-            float d = (i < S - 1) ? (zl[i + 1] - zl[i]) : 0.f;
-            float a = 1.f - expf(-sig[i] * d);
-            alpha[c] = a;
-            delta[c] = d;
-            prod *= (double)(1.f - a);
-        }
-    }
-    double before = wave_excl_prod(prod, lane);
-    float wgt[kMaxC], g[kMaxC];
-    double gw_local = 0.0;
-#pragma unroll
-    for (int c = 0; c < kMaxC; ++c) {
-        int i = lane * C + c;
-        wgt[c] = 0.f;
-        g[c] = 0.f;
-        if (c < C && i < S) {
-            wgt[c] = alpha[c] * (float)(before * om_local[c]);
-            g[c] = dw[i] + gi0 * (col[i * 3] - b0) + gi1 * (col[i * 3 + 1] - b1) + gi2 * (col[i * 3 + 2] - b2);
-            gw_local += (double)g[c] * (double)wgt[c];
-        }
-    }
-    double after = wave_excl_suffix_sum(gw_local, lane);  // sum over lanes above
-    // walk the chunk from its last sample down, carrying the suffix sum
-    double suffix = after;
-    float ds[kMaxC];
-#pragma unroll
-    for (int c = kMaxC - 1; c >= 0; --c) {
-        int i = lane * C + c;
-        ds[c] = 0.f;
-        if (c < C && i < S) {
-            double t_next = before * om_local[c] * (double)(1.f - alpha[c]);
-            ds[c] = delta[c] * (float)((double)g[c] * t_next - suffix);
-            suffix += (double)g[c] * (double)wgt[c];
-        }
-    }
-    __syncthreads();  // all reads of col[] done before it is overwritten with drgb
-#pragma unroll
-    for (int c = 0; c < kMaxC; ++c) {
-        int i = lane * C + c;
-        if (c < C && i < S) {
-            s_sig[wv][i] = ds[c];
-            col[i * 3] = wgt[c] * gi0;
-            col[i * 3 + 1] = wgt[c] * gi1;
-            col[i * 3 + 2] = wgt[c] * gi2;
-        }
-    }
-    __syncthreads();
-    if (!live) return;
-    for (int i = lane; i < S; i += kWave) dsigma[ray * S + i] = s_sig[wv][i];
-    for (int i = lane; i < S * 3; i += kWave) drgb[ray * S * 3 + i] = col[i];
+    for (int c = 0; c < C; ++c)
+        g[c] = (lane * C + c < S) ? dw[c] + gi0 * (col[c * 3] - b0) + gi1 * (col[c * 3 + 1] - b1) + gi2 * (col[c * 3 + 2] - b2) : 0.f;
+    composite_grads<C>(t, g, gi0, gi1, gi2, S, lane, ds, dc);
+    store_run<C, VEC, W>(dsigma + ray * S, ds, lane * C, S);
+    store_run<3 * C, VEC, W>(drgb + ray * S * 3, dc, lane * 3 * C, 3 * S);
 }
 
 // ------------------------------------------------------------------------------------------
-// R11: losses (helpers.py:21-32, trainer.py:153-169) and their gradients, one wavefront per ray.
+// R11: losses (helpers.py:21-32, trainer.py:153-169) and their gradients.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void losses_kernel(const float* __restrict__ image, const float* __restrict__ gt,
-                                                     const float* __restrict__ weights, const float* __restrict__ zs,
-                                                     int64_t n_rays, int S, float lam_dist, float lam_depth,
-                                                     float grad_scale, int sorted, double* __restrict__ sums,
-                                                     float* __restrict__ dimage, float* __restrict__ dweights) {
-    __shared__ float s_w[kRaysPerBlock][kMaxS];
-    __shared__ float s_s[kRaysPerBlock][kMaxS];
-    __shared__ double s_part[kRaysPerBlock][4];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int C = (S + kWave - 1) / kWave;
-    const bool need_ws = weights != nullptr;
-    const float *w = s_w[wv], *s = s_s[wv];
-    double l_rgb = 0, l_mse = 0, l_dist = 0, l_depth = 0;
-    const double inv_n = 1.0 / (double)n_rays;
-    // A workgroup walks the rays with a grid-sized stride and adds its five totals once at the end: the fp64 atomics of
-    // all workgroups land on one 64-byte line and serialise there (4 ns each: 20 us with a workgroup per four rays).
-    for (int64_t base = (int64_t)blockIdx.x * kRaysPerBlock; base < n_rays; base += (int64_t)gridDim.x * kRaysPerBlock) {
-    int64_t ray = base + wv;
-    const bool live = ray < n_rays;
-    if (!live) ray = n_rays - 1;
-    __syncthreads();        // the previous round's readers of this wave's rows are done
-    if (need_ws) {
-        load_row(s_w[wv], weights + ray * S, S, lane);
-        load_row(s_s[wv], zs + ray * S, S, lane);
-    }
-    __syncthreads();
-    double r_rgb = 0, r_mse = 0, r_dist = 0, r_depth = 0;
-    // Huber(delta = 0.1), mean over N*3
-    if (lane < 3) {
-        float d = image[ray * 3 + lane] - gt[ray * 3 + lane];
-        float ad = fabsf(d);
-        const float hd = 0.1f;
-        r_rgb = ad <= hd ? 0.5 * (double)d * d : (double)hd * ((double)ad - 0.5 * hd);
-        r_mse = (double)d * d;
-        if (dimage && live) {
-            float gr = ad <= hd ? d : (d > 0 ? hd : -hd);
-            dimage[ray * 3 + lane] = grad_scale * gr * (float)(inv_n / 3.0);
+// Huber(delta = 0.1) and squared error of one colour channel (lanes 0..2 of a ray's wave)
+__device__ __forceinline__ void huber(float d, double& l_rgb, double& l_mse, float& grad) {
+    const float ad = fabsf(d);
+    const float hd = 0.1f;
+    l_rgb = ad <= hd ? 0.5 * (double)d * d : (double)hd * ((double)ad - 0.5 * hd);
+    l_mse = (double)d * d;
+    grad = ad <= hd ? d : (d > 0 ? hd : -hd);
+}
+
+// sum_ij w_i w_j |s_i - s_j| = 2 sum_i w_i (s_i W_<i - WS_<i) for non-decreasing s, and sum_i w_i (1 - s_i); gdw (nullable):
+// d(distortion)/d(w_i)
+template <int C, bool GRAD>
+__device__ __forceinline__ void dist_depth(const float (&w)[C], const float (&s)[C], int S, int lane, double& r_dist,
+                                           double& r_depth, float (&gdw)[C]) {
+    double lw = 0, lws = 0;
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+        if (lane * C + c < S) { lw += (double)w[c]; lws += (double)w[c] * (double)s[c]; }
+    double pw = wave_excl_sum(lw, lane), pws = wave_excl_sum(lws, lane);
+    double tw = 0, tws = 0;
+    if (GRAD) { tw = wave_sum(lw); tws = wave_sum(lws); }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        gdw[c] = 0.f;
+        if (lane * C + c < S) {
+            const double wi = w[c], si = s[c];
+            r_dist += 2.0 * wi * (si * pw - pws);
+            if (GRAD) {
+                const double aw = tw - pw - wi, aws = tws - pws - wi * si;  // strictly after i
+                gdw[c] = (float)(2.0 * (si * pw - pws + aws - si * aw));
+            }
+            r_depth += wi * (1.0 - si);
+            pw += wi;
+            pws += wi * si;
         }
     }
-    if (need_ws) {
-        float gdw[kMaxC];
-        if (sorted) {
-            // sum_ij w_i w_j |s_i - s_j| = 2 sum_i w_i (s_i W_<i - WS_<i)  for non-decreasing s
-            double lw = 0, lws = 0;
-#pragma unroll
-            for (int c = 0; c < kMaxC; ++c) {
-                int i = lane * C + c;
-                if (c < C && i < S) { lw += (double)w[i]; lws += (double)w[i] * (double)s[i]; }
-            }
-            double pw = wave_excl_sum(lw, lane), pws = wave_excl_sum(lws, lane);
-            double tw = wave_sum(lw), tws = wave_sum(lws);
-#pragma unroll
-            for (int c = 0; c < kMaxC; ++c) {
-                int i = lane * C + c;
-                gdw[c] = 0.f;
-                if (c < C && i < S) {
-                    double wi = w[i], si = s[i];
-                    r_dist += 2.0 * wi * (si * pw - pws);
-                    double aw = tw - pw - wi, aws = tws - pws - wi * si;  // strictly after i
-                    gdw[c] = (float)(2.0 * (si * pw - pws + aws - si * aw));
-                    r_depth += wi * (1.0 - si);
-                    pw += wi;
-                    pws += wi * si;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < kMaxC; ++c) {
-                int i = lane * C + c;
-                gdw[c] = 0.f;
-                if (c < C && i < S) {
-                    double acc = 0;
-                    for (int j = 0; j < S; ++j) acc += (double)w[j] * fabs((double)s[i] - (double)s[j]);
-                    r_dist += (double)w[i] * acc;
-                    gdw[c] = (float)(2.0 * acc);
-                    r_depth += (double)w[i] * (1.0 - (double)s[i]);
-                }
-            }
-        }
-        if (dweights && live) {
-            const float cd = grad_scale * lam_dist * (float)inv_n;
-            const float cz = grad_scale * lam_depth * (float)(inv_n / (double)S);
-#pragma unroll
-            for (int c = 0; c < kMaxC; ++c) {
-                int i = lane * C + c;
-                if (c < C && i < S) dweights[ray * S + i] = cd * gdw[c] + cz * (1.f - s[i]);
-            }
-        }
-    }
-    if (live) { l_rgb += r_rgb; l_mse += r_mse; l_dist += r_dist; l_depth += r_depth; }
-    }
+}
+
+// four per-wave partial sums -> one row per workgroup (s_part: [kRaysPerBlock][4] doubles of LDS)
+__device__ __forceinline__ void loss_partials(double (*s_part)[4], double l_rgb, double l_dist, double l_depth, double l_mse,
+                                              double inv_n, int S, int wv, int lane) {
     l_rgb = wave_sum(l_rgb); l_mse = wave_sum(l_mse); l_dist = wave_sum(l_dist); l_depth = wave_sum(l_depth);
     if (lane == 0) {
         s_part[wv][0] = l_rgb * inv_n / 3.0;
@@ -585,6 +537,49 @@ __global__ __launch_bounds__(256) void losses_kernel(const float* __restrict__ i
         s_part[wv][3] = l_mse * inv_n / 3.0;
     }
     __syncthreads();
+}
+
+// sorted form, rows in registers.  A workgroup walks the rays with a grid-sized stride and adds its five totals once at
+// the end: the fp64 atomics of all workgroups land on one 64-byte line and serialise there (4 ns each).
+template <int C, bool VEC>
+__global__ __launch_bounds__(256) void losses_sorted_kernel(const float* __restrict__ image, const float* __restrict__ gt,
+                                                            const float* __restrict__ weights, const float* __restrict__ zs,
+                                                            int64_t n_rays, int S, float lam_dist, float lam_depth,
+                                                            float grad_scale, double* __restrict__ sums,
+                                                            float* __restrict__ dimage, float* __restrict__ dweights) {
+    __shared__ double s_part[kRaysPerBlock][4];
+    constexpr int W = VecW<C>::W;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double l_rgb = 0, l_mse = 0, l_dist = 0, l_depth = 0;
+    const double inv_n = 1.0 / (double)n_rays;
+    for (int64_t base = (int64_t)blockIdx.x * kRaysPerBlock; base < n_rays; base += (int64_t)gridDim.x * kRaysPerBlock) {
+        const int64_t ray = base + wv;
+        if (ray >= n_rays) continue;
+        float w[C], s[C], gdw[C];
+        load_run<C, VEC, W>(w, weights + ray * S, lane * C, S);
+        load_run<C, VEC, W>(s, zs + ray * S, lane * C, S);
+        if (lane < 3) {
+            double r_rgb, r_mse;
+            float gr;
+            huber(image[ray * 3 + lane] - gt[ray * 3 + lane], r_rgb, r_mse, gr);
+            l_rgb += r_rgb;
+            l_mse += r_mse;
+            if (dimage) dimage[ray * 3 + lane] = grad_scale * gr * (float)(inv_n / 3.0);
+        }
+        double r_dist = 0, r_depth = 0;
+        dist_depth<C, true>(w, s, S, lane, r_dist, r_depth, gdw);
+        l_dist += r_dist;
+        l_depth += r_depth;
+        if (dweights) {
+            const float cd = grad_scale * lam_dist * (float)inv_n;
+            const float cz = grad_scale * lam_depth * (float)(inv_n / (double)S);
+            float o[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) o[c] = cd * gdw[c] + cz * (1.f - s[c]);
+            store_run<C, VEC, W>(dweights + ray * S, o, lane * C, S);
+        }
+    }
+    loss_partials(s_part, l_rgb, l_dist, l_depth, l_mse, inv_n, S, wv, lane);
     if (threadIdx.x < 4) {
         double v = s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
         atomicAdd(&sums[threadIdx.x], v);
@@ -598,128 +593,151 @@ __global__ __launch_bounds__(256) void losses_kernel(const float* __restrict__ i
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// R10 + R11 fused for the training step: compositing, the three losses and (second kernel) the backward of both.
-// The arithmetic is composite_fwd_kernel's, losses_kernel's (sorted form) and composite_bwd_kernel's, operation for
-// operation -- the same image, weights and gradients bit for bit; only the order in which the workgroups add their loss
-// totals differs.  What goes away: the weights / zlog_s round trip through HBM between the kernels, dimage / dweights
-// altogether, and five small launches (zeroing, fp64 -> fp32 copy, two multiplies by d(loss), the separate compositing).
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void composite_loss_fwd_kernel(
-    const float* __restrict__ sigma, const float* __restrict__ rgb, const float* __restrict__ z, const float* __restrict__ zlog,
-    const float* __restrict__ bg, const float* __restrict__ gt, int64_t n_rays, int S, float zlog_lo, float zlog_range,
-    float* __restrict__ image, float* __restrict__ invdepth, float* __restrict__ weights,
-    float* __restrict__ zlog_s, double* __restrict__ partials) {
-    __shared__ float s_sig[kRaysPerBlock][kMaxS];
-    __shared__ float s_zl[kRaysPerBlock][kMaxS];
-    __shared__ float s_z[kRaysPerBlock][kMaxS];
-    __shared__ float s_rgb[kRaysPerBlock][kMaxS * 3];
+// The general form: colour-only calls (weights == nullptr: psnr, criterion_rgb) and the O(S^2) distortion sum for rows
+// that are not sorted (helpers.py:23-25 as written); rows staged in LDS, kMaxS samples at most.
+constexpr int kMaxC = kMaxS / kWave;
+__device__ __forceinline__ void load_row(float* dst, const float* src, int n, int lane) {
+    for (int i = lane; i < n; i += kWave) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(256) void losses_kernel(const float* __restrict__ image, const float* __restrict__ gt,
+                                                     const float* __restrict__ weights, const float* __restrict__ zs,
+                                                     int64_t n_rays, int S, float lam_dist, float lam_depth,
+                                                     float grad_scale, double* __restrict__ sums,
+                                                     float* __restrict__ dimage, float* __restrict__ dweights) {
+    __shared__ float s_w[kRaysPerBlock][kMaxS];
+    __shared__ float s_s[kRaysPerBlock][kMaxS];
     __shared__ double s_part[kRaysPerBlock][4];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int C = (S + kWave - 1) / kWave;
-    const double inv_n = 1.0 / (double)n_rays;
-    const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
+    const bool need_ws = weights != nullptr;
+    const float *w = s_w[wv], *s = s_s[wv];
     double l_rgb = 0, l_mse = 0, l_dist = 0, l_depth = 0;
+    const double inv_n = 1.0 / (double)n_rays;
     for (int64_t base = (int64_t)blockIdx.x * kRaysPerBlock; base < n_rays; base += (int64_t)gridDim.x * kRaysPerBlock) {
         int64_t ray = base + wv;
         const bool live = ray < n_rays;
         if (!live) ray = n_rays - 1;
         __syncthreads();        // the previous round's readers of this wave's rows are done
-        load_row(s_sig[wv], sigma + ray * S, S, lane);
-        load_row(s_zl[wv], zlog + ray * S, S, lane);
-        load_row(s_z[wv], z + ray * S, S, lane);
-        load_row(s_rgb[wv], rgb + ray * S * 3, S * 3, lane);
+        if (need_ws) {
+            load_row(s_w[wv], weights + ray * S, S, lane);
+            load_row(s_s[wv], zs + ray * S, S, lane);
+        }
         __syncthreads();
-        const float *sig = s_sig[wv], *zl = s_zl[wv], *zz = s_z[wv], *col = s_rgb[wv];
-        // ---- composite_fwd_kernel ----
-        float alpha[kMaxC];
-        double om_local[kMaxC];
-        double prod = 1.0;
+        double r_rgb = 0, r_mse = 0, r_dist = 0, r_depth = 0;
+        if (lane < 3) {
+            float gr;
+            huber(image[ray * 3 + lane] - gt[ray * 3 + lane], r_rgb, r_mse, gr);
+            if (dimage && live) dimage[ray * 3 + lane] = grad_scale * gr * (float)(inv_n / 3.0);
+        }
+        if (need_ws) {
+            float gdw[kMaxC];
 #pragma unroll
-        for (int c = 0; c < kMaxC; ++c) {
-            int i = lane * C + c;
-            alpha[c] = 0.f;
-            om_local[c] = prod;
-            if (c < C && i < S) {
-                float delta = (i < S - 1) ? (zl[i + 1] - zl[i]) : 0.f;
-                float a = 1.f - expf(-sig[i] * delta);
-                alpha[c] = a;
-                prod *= (double)(1.f - a);
+            for (int c = 0; c < kMaxC; ++c) {
+                int i = lane * C + c;
+                gdw[c] = 0.f;
+                if (c < C && i < S) {
+                    double acc = 0;
+                    for (int j = 0; j < S; ++j) acc += (double)w[j] * fabs((double)s[i] - (double)s[j]);
+                    r_dist += (double)w[i] * acc;
+                    gdw[c] = (float)(2.0 * acc);
+                    r_depth += (double)w[i] * (1.0 - (double)s[i]);
+                }
+            }
+            if (dweights && live) {
+                const float cd = grad_scale * lam_dist * (float)inv_n;
+                const float cz = grad_scale * lam_depth * (float)(inv_n / (double)S);
+#pragma unroll
+                for (int c = 0; c < kMaxC; ++c) {
+                    int i = lane * C + c;
+                    if (c < C && i < S) dweights[ray * S + i] = cd * gdw[c] + cz * (1.f - s[i]);
+                }
             }
         }
-        double before = wave_excl_prod(prod, lane);
+        if (live) { l_rgb += r_rgb; l_mse += r_mse; l_dist += r_dist; l_depth += r_depth; }
+    }
+    loss_partials(s_part, l_rgb, l_dist, l_depth, l_mse, inv_n, S, wv, lane);
+    if (threadIdx.x < 4) {
+        double v = s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
+        atomicAdd(&sums[threadIdx.x], v);
+    } else if (threadIdx.x == 4) {
+        double v = 0;
+        for (int k = 0; k < 4; ++k) v += s_part[k][0] + (double)lam_dist * s_part[k][1] + (double)lam_depth * s_part[k][2];
+        atomicAdd(&sums[4], v);
+        if (!(fabs(v) <= 1.7976931348623157e308)) atomicAdd(&sums[5], 1.0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// R10 + R11 fused for the training step: compositing, the three losses and (second kernel) the backward of both.
+// The arithmetic is composite_fwd_kernel's, losses_sorted_kernel's and composite_bwd_kernel's, operation for
+// operation -- the same image, weights and gradients bit for bit; only the order in which the workgroups add their loss
+// totals differs.  What goes away: the weights / zlog_s round trip through HBM between the kernels, dimage / dweights
+// altogether, and five small launches (zeroing, fp64 -> fp32 copy, two multiplies by d(loss), the separate compositing).
+// ------------------------------------------------------------------------------------------
+template <int C, bool VEC>
+__global__ __launch_bounds__(256) void composite_loss_fwd_kernel(
+    const float* __restrict__ sigma, const float* __restrict__ rgb, const float* __restrict__ z, const float* __restrict__ zlog,
+    const float* __restrict__ bg, const float* __restrict__ gt, int64_t n_rays, int S, float zlog_lo, float zlog_range,
+    float* __restrict__ image, float* __restrict__ invdepth, float* __restrict__ weights,
+    float* __restrict__ zlog_s, double* __restrict__ partials) {
+    __shared__ double s_part[kRaysPerBlock][4];
+    constexpr int W = VecW<C>::W;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const double inv_n = 1.0 / (double)n_rays;
+    const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
+    double l_rgb = 0, l_mse = 0, l_dist = 0, l_depth = 0;
+    for (int64_t base = (int64_t)blockIdx.x * kRaysPerBlock; base < n_rays; base += (int64_t)gridDim.x * kRaysPerBlock) {
+        const int64_t ray = base + wv;
+        if (ray >= n_rays) continue;
+        float sig[C], zl[C], zz[C], col[3 * C];
+        load_run<C, VEC, W>(sig, sigma + ray * S, lane * C, S);
+        load_run<C, VEC, W>(zl, zlog + ray * S, lane * C, S);
+        load_run<C, VEC, W>(zz, z + ray * S, lane * C, S);
+        load_run<3 * C, VEC, W>(col, rgb + ray * S * 3, lane * 3 * C, 3 * S);
+        // ---- composite_fwd_kernel ----
+        Trans<C> t;
+        transmittance(t, sig, zl, S, lane);
         double ar = 0, ag = 0, ab = 0, ainv = 0, aw = 0;
-        float wgt[kMaxC], ss[kMaxC];
+        float ss[C];
 #pragma unroll
-        for (int c = 0; c < kMaxC; ++c) {
-            int i = lane * C + c;
-            wgt[c] = 0.f;
+        for (int c = 0; c < C; ++c) {
             ss[c] = 0.f;
-            if (c < C && i < S) {
-                wgt[c] = alpha[c] * (float)(before * om_local[c]);
-                ss[c] = (zl[i] - zlog_lo) / zlog_range;
-                ar += (double)(wgt[c] * col[i * 3]);
-                ag += (double)(wgt[c] * col[i * 3 + 1]);
-                ab += (double)(wgt[c] * col[i * 3 + 2]);
-                ainv += (double)(wgt[c] / zz[i]);
-                aw += (double)wgt[c];
+            if (lane * C + c < S) {
+                const float wgt = t.wgt[c];
+                ss[c] = (zl[c] - zlog_lo) / zlog_range;
+                ar += (double)(wgt * col[c * 3]);
+                ag += (double)(wgt * col[c * 3 + 1]);
+                ab += (double)(wgt * col[c * 3 + 2]);
+                ainv += (double)(wgt / zz[c]);
+                aw += (double)wgt;
             }
         }
         ar = wave_sum(ar); ag = wave_sum(ag); ab = wave_sum(ab); ainv = wave_sum(ainv); aw = wave_sum(aw);
         const float rest = 1.f - (float)aw;
         const float im0 = (float)ar + rest * b0, im1 = (float)ag + rest * b1, im2 = (float)ab + rest * b2;
-        if (live) {
-#pragma unroll
-            for (int c = 0; c < kMaxC; ++c) {
-                int i = lane * C + c;
-                if (c < C && i < S) {
-                    weights[ray * S + i] = wgt[c];
-                    if (zlog_s) zlog_s[ray * S + i] = ss[c];
-                }
-            }
-            if (lane == 0) {
-                image[ray * 3] = im0; image[ray * 3 + 1] = im1; image[ray * 3 + 2] = im2;
-                invdepth[ray] = (float)ainv;
-            }
+        store_run<C, VEC, W>(weights + ray * S, t.wgt, lane * C, S);
+        if (zlog_s) store_run<C, VEC, W>(zlog_s + ray * S, ss, lane * C, S);
+        if (lane == 0) {
+            image[ray * 3] = im0; image[ray * 3 + 1] = im1; image[ray * 3 + 2] = im2;
+            invdepth[ray] = (float)ainv;
         }
-        // ---- losses_kernel (sorted form) on the same registers ----
-        double r_rgb = 0, r_mse = 0, r_dist = 0, r_depth = 0;
+        // ---- losses_sorted_kernel on the same registers ----
         if (lane < 3) {
             const float im = lane == 0 ? im0 : (lane == 1 ? im1 : im2);
-            float d = im - gt[ray * 3 + lane];
-            float ad = fabsf(d);
-            const float hd = 0.1f;
-            r_rgb = ad <= hd ? 0.5 * (double)d * d : (double)hd * ((double)ad - 0.5 * hd);
-            r_mse = (double)d * d;
+            double r_rgb, r_mse;
+            float gr;
+            huber(im - gt[ray * 3 + lane], r_rgb, r_mse, gr);
+            l_rgb += r_rgb;
+            l_mse += r_mse;
         }
-        double lw = 0, lws = 0;
-#pragma unroll
-        for (int c = 0; c < kMaxC; ++c) {
-            int i = lane * C + c;
-            if (c < C && i < S) { lw += (double)wgt[c]; lws += (double)wgt[c] * (double)ss[c]; }
-        }
-        double pw = wave_excl_sum(lw, lane), pws = wave_excl_sum(lws, lane);
-#pragma unroll
-        for (int c = 0; c < kMaxC; ++c) {
-            int i = lane * C + c;
-            if (c < C && i < S) {
-                double wi = wgt[c], si = ss[c];
-                r_dist += 2.0 * wi * (si * pw - pws);
-                r_depth += wi * (1.0 - si);
-                pw += wi;
-                pws += wi * si;
-            }
-        }
-        if (live) { l_rgb += r_rgb; l_mse += r_mse; l_dist += r_dist; l_depth += r_depth; }
+        double r_dist = 0, r_depth = 0;
+        float unused[C];
+        dist_depth<C, false>(t.wgt, ss, S, lane, r_dist, r_depth, unused);
+        l_dist += r_dist;
+        l_depth += r_depth;
     }
-    l_rgb = wave_sum(l_rgb); l_mse = wave_sum(l_mse); l_dist = wave_sum(l_dist); l_depth = wave_sum(l_depth);
-    if (lane == 0) {
-        s_part[wv][0] = l_rgb * inv_n / 3.0;
-        s_part[wv][1] = l_dist * inv_n;
-        s_part[wv][2] = l_depth * inv_n / (double)S;
-        s_part[wv][3] = l_mse * inv_n / 3.0;
-    }
-    __syncthreads();
+    loss_partials(s_part, l_rgb, l_dist, l_depth, l_mse, inv_n, S, wv, lane);
     // one row of four partial sums per workgroup, plain stores: composite_loss_finish_kernel adds the rows up in a fixed
     // order (no same-line fp64 atomics from a thousand workgroups, no device-scope fence, and a reproducible total)
     if (threadIdx.x < 4)
@@ -755,154 +773,117 @@ __global__ __launch_bounds__(256) void composite_loss_finish_kernel(const double
     }
 }
 
+// nonfinite (nullable): the step's non-finite flag (sums[5] of the forward call); raised when a gradient this kernel
+// writes is NaN / Inf although the loss was finite (GradScaler.step skips on non-finite GRADIENTS, trainer.py:134-136)
+template <int C, bool VEC>
 __global__ __launch_bounds__(256) void composite_loss_bwd_kernel(
     const float* __restrict__ sigma, const float* __restrict__ rgb, const float* __restrict__ zlog, const float* __restrict__ bg,
     const float* __restrict__ gt, const float* __restrict__ image, const float* __restrict__ dout, int64_t n_rays, int S,
-    float zlog_lo, float zlog_range, float lam_dist, float lam_depth, float* __restrict__ dsigma, float* __restrict__ drgb) {
-    __shared__ float s_sig[kRaysPerBlock][kMaxS];
-    __shared__ float s_zl[kRaysPerBlock][kMaxS];
-    __shared__ float s_rgb[kRaysPerBlock][kMaxS * 3];
+    float zlog_lo, float zlog_range, float lam_dist, float lam_depth, float* __restrict__ dsigma, float* __restrict__ drgb,
+    double* __restrict__ nonfinite) {
+    constexpr int W = VecW<C>::W;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wv;
-    const bool live = ray < n_rays;
-    if (!live) ray = n_rays - 1;
-    const int C = (S + kWave - 1) / kWave;
-    load_row(s_sig[wv], sigma + ray * S, S, lane);
-    load_row(s_zl[wv], zlog + ray * S, S, lane);
-    load_row(s_rgb[wv], rgb + ray * S * 3, S * 3, lane);
-    __syncthreads();
-    const float *sig = s_sig[wv], *zl = s_zl[wv];
-    float* col = s_rgb[wv];
+    const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wv;
+    if (ray >= n_rays) return;
+    float sig[C], zl[C], col[3 * C];
+    load_run<C, VEC, W>(sig, sigma + ray * S, lane * C, S);
+    load_run<C, VEC, W>(zl, zlog + ray * S, lane * C, S);
+    load_run<3 * C, VEC, W>(col, rgb + ray * S * 3, lane * 3 * C, 3 * S);
     const float up = dout ? dout[0] : 1.f;
     const double inv_n = 1.0 / (double)n_rays;
-    // d(loss)/d(image): Huber gradient, as losses_kernel writes it (grad_scale = 1), times the upstream gradient
+    // d(loss)/d(image): Huber gradient, as losses_sorted_kernel writes it (grad_scale = 1), times the upstream gradient
     float gi[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        float d = image[ray * 3 + k] - gt[ray * 3 + k];
-        float ad = fabsf(d);
-        const float hd = 0.1f;
-        float gr = ad <= hd ? d : (d > 0 ? hd : -hd);
+        double r_rgb, r_mse;
+        float gr;
+        huber(image[ray * 3 + k] - gt[ray * 3 + k], r_rgb, r_mse, gr);
         gi[k] = (1.0f * gr * (float)(inv_n / 3.0)) * up;
     }
     const float gi0 = gi[0], gi1 = gi[1], gi2 = gi[2];
     const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
-    float alpha[kMaxC], delta[kMaxC];
-    double om_local[kMaxC];
-    double prod = 1.0;
+    Trans<C> t;
+    transmittance(t, sig, zl, S, lane);
+    float ss[C], gdw[C], g[C];
 #pragma unroll
-    for (int c = 0; c < kMaxC; ++c) {
-        int i = lane * C + c;
-        alpha[c] = 0.f;
-        delta[c] = 0.f;
-        om_local[c] = prod;
-        if (c < C && i < S) {
-            float d = (i < S - 1) ? (zl[i + 1] - zl[i]) : 0.f;
-            float a = 1.f - expf(-sig[i] * d);
-            alpha[c] = a;
-            delta[c] = d;
-            prod *= (double)(1.f - a);
-        }
-    }
-    double before = wave_excl_prod(prod, lane);
-    float wgt[kMaxC], ss[kMaxC], g[kMaxC];
-    double lw = 0, lws = 0;
-#pragma unroll
-    for (int c = 0; c < kMaxC; ++c) {
-        int i = lane * C + c;
-        wgt[c] = 0.f;
-        ss[c] = 0.f;
-        if (c < C && i < S) {
-            wgt[c] = alpha[c] * (float)(before * om_local[c]);
-            ss[c] = (zl[i] - zlog_lo) / zlog_range;
-            lw += (double)wgt[c];
-            lws += (double)wgt[c] * (double)ss[c];
-        }
-    }
-    // d(loss)/d(weights): losses_kernel's sorted form
-    double pw = wave_excl_sum(lw, lane), pws = wave_excl_sum(lws, lane);
-    const double tw = wave_sum(lw), tws = wave_sum(lws);
+    for (int c = 0; c < C; ++c) ss[c] = (lane * C + c < S) ? (zl[c] - zlog_lo) / zlog_range : 0.f;
+    // d(loss)/d(weights): losses_sorted_kernel's form
+    double r_dist = 0, r_depth = 0;
+    dist_depth<C, true>(t.wgt, ss, S, lane, r_dist, r_depth, gdw);
     const float cd = 1.0f * lam_dist * (float)inv_n;
     const float cz = 1.0f * lam_depth * (float)(inv_n / (double)S);
-    double gw_local = 0.0;
 #pragma unroll
-    for (int c = 0; c < kMaxC; ++c) {
-        int i = lane * C + c;
+    for (int c = 0; c < C; ++c) {
         g[c] = 0.f;
-        if (c < C && i < S) {
-            const double wi = wgt[c], si = ss[c];
-            const double aw = tw - pw - wi, aws = tws - pws - wi * si;      // strictly after i
-            const float gdw = (float)(2.0 * (si * pw - pws + aws - si * aw));
-            const float dw = (cd * gdw + cz * (1.f - ss[c])) * up;
-            pw += wi;
-            pws += wi * si;
-            g[c] = dw + gi0 * (col[i * 3] - b0) + gi1 * (col[i * 3 + 1] - b1) + gi2 * (col[i * 3 + 2] - b2);
-            gw_local += (double)g[c] * (double)wgt[c];
+        if (lane * C + c < S) {
+            const float dw = (cd * gdw[c] + cz * (1.f - ss[c])) * up;
+            g[c] = dw + gi0 * (col[c * 3] - b0) + gi1 * (col[c * 3 + 1] - b1) + gi2 * (col[c * 3 + 2] - b2);
         }
     }
     // ---- composite_bwd_kernel from here ----
-    double after = wave_excl_suffix_sum(gw_local, lane);
-    double suffix = after;
-    float ds[kMaxC];
-#pragma unroll
-    for (int c = kMaxC - 1; c >= 0; --c) {
-        int i = lane * C + c;
-        ds[c] = 0.f;
-        if (c < C && i < S) {
-            double t_next = before * om_local[c] * (double)(1.f - alpha[c]);
-            ds[c] = delta[c] * (float)((double)g[c] * t_next - suffix);
-            suffix += (double)g[c] * (double)wgt[c];
-        }
-    }
-    __syncthreads();  // all reads of col[] done before it is overwritten with drgb
-#pragma unroll
-    for (int c = 0; c < kMaxC; ++c) {
-        int i = lane * C + c;
-        if (c < C && i < S) {
-            s_sig[wv][i] = ds[c];
-            col[i * 3] = wgt[c] * gi0;
-            col[i * 3 + 1] = wgt[c] * gi1;
-            col[i * 3 + 2] = wgt[c] * gi2;
-        }
-    }
-    __syncthreads();
-    if (!live) return;
-    for (int i = lane; i < S; i += kWave) dsigma[ray * S + i] = s_sig[wv][i];
-    for (int i = lane; i < S * 3; i += kWave) drgb[ray * S * 3 + i] = col[i];
+    float ds[C], dc[3 * C];
+    const bool bad = composite_grads<C>(t, g, gi0, gi1, gi2, S, lane, ds, dc);
+    store_run<C, VEC, W>(dsigma + ray * S, ds, lane * C, S);
+    store_run<3 * C, VEC, W>(drgb + ray * S * 3, dc, lane * 3 * C, 3 * S);
+    if (bad && nonfinite) *nonfinite = 1.0;     // (every writer stores the same value)
 }
 
 // inference.py:97-105: one-hot of the first sample whose running weight sum reaches thresh
+template <int C, bool VEC>
 __global__ __launch_bounds__(256) void cum_thresh_kernel(const float* __restrict__ weights, int64_t n_rays, int S,
                                                          float thresh, float* __restrict__ out) {
-    __shared__ float s_w[kRaysPerBlock][kMaxS];
+    constexpr int W = VecW<C>::W;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wv;
-    const bool live = ray < n_rays;
-    if (!live) ray = n_rays - 1;
-    const int C = (S + kWave - 1) / kWave;
-    load_row(s_w[wv], weights + ray * S, S, lane);
-    __syncthreads();
+    const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wv;
+    if (ray >= n_rays) return;
+    float w[C];
+    load_run<C, VEC, W>(w, weights + ray * S, lane * C, S);
     double local = 0;
 #pragma unroll
-    for (int c = 0; c < kMaxC; ++c) {
-        int i = lane * C + c;
-        if (c < C && i < S) local += (double)s_w[wv][i];
-    }
+    for (int c = 0; c < C; ++c) local += (double)w[c];
     double run = wave_excl_sum(local, lane);
     int first = S;  // first index with (float)cumsum >= thresh in this lane's chunk
 #pragma unroll
-    for (int c = 0; c < kMaxC; ++c) {
-        int i = lane * C + c;
-        if (c < C && i < S) {
-            run += (double)s_w[wv][i];
+    for (int c = 0; c < C; ++c) {
+        const int i = lane * C + c;
+        if (i < S) {
+            run += (double)w[c];
             if ((float)run >= thresh && first == S) first = i;
         }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) first = min(first, __shfl_xor(first, off, kWave));
-    if (!live) return;
-    for (int i = lane; i < S; i += kWave) out[ray * S + i] = (i == first) ? 1.f : 0.f;
+    float o[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) o[c] = (lane * C + c == first) ? 1.f : 0.f;
+    store_run<C, VEC, W>(out + ray * S, o, lane * C, S);
 }
+
+// Launch shape of a per-ray kernel: samples per lane and whether the rows can move as vectors
+struct RowShape { int C; bool vec; };
+static RowShape row_shape(int S, int64_t extra_stride, std::initializer_list<const void*> rows) {
+    RowShape r;
+    r.C = S <= 64 ? 1 : (S <= 128 ? 2 : (S <= 256 ? 4 : 8));
+    const int W = r.C < 4 ? r.C : 4;
+    r.vec = W > 1 && S % W == 0 && extra_stride % W == 0;
+    for (const void* p : rows)
+        if (p && (((uintptr_t)p) & (uintptr_t)(4 * W - 1))) r.vec = false;
+    return r;
+}
+
+// fn(std::integral_constant<int, C>, std::bool_constant<VEC>) launches the instantiation for the shape
+template <class Fn>
+static void row_dispatch(RowShape s, Fn&& fn) {
+    using std::integral_constant;
+    switch (s.C) {
+        case 1: fn(integral_constant<int, 1>{}, std::false_type{}); break;
+        case 2: if (s.vec) fn(integral_constant<int, 2>{}, std::true_type{}); else fn(integral_constant<int, 2>{}, std::false_type{}); break;
+        case 4: if (s.vec) fn(integral_constant<int, 4>{}, std::true_type{}); else fn(integral_constant<int, 4>{}, std::false_type{}); break;
+        default: if (s.vec) fn(integral_constant<int, 8>{}, std::true_type{}); else fn(integral_constant<int, 8>{}, std::false_type{}); break;
+    }
+}
+#define ROW_C decltype(c_)::value
+#define ROW_V decltype(v_)::value
 
 __global__ void uniform_noise_kernel(uint64_t seed, uint64_t counter, int64_t n, float* __restrict__ out) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -976,8 +957,10 @@ int nerf_coarse_weights(const float* sigma, const float* zlog, int64_t zlog_stri
     NERF_REQUIRE(check_ray_args(n_rays, n_samples) != 2, "n_samples must be in [1, 512]");
     if (n_rays <= 0) return n_rays == 0 ? 0 : NERF_EINVAL;
     SegCfg seg = {};
-    ray_sampling_kernel<0><<<(unsigned)ceil_div64(n_rays, kRaysPerBlock), 256, 0, S_(stream)>>>(
-        sigma, zlog, zlog_stride, nullptr, nullptr, n_rays, n_samples, 0, 0.f, seg, weights, nullptr, nullptr, 0, 0);
+    row_dispatch(row_shape(n_samples, zlog_stride, {sigma, zlog, weights}), [&](auto c_, auto v_) {
+        ray_sampling_kernel<0, ROW_C, ROW_V><<<(unsigned)ceil_div64(n_rays, kRaysPerBlock), 256, 0, S_(stream)>>>(
+            sigma, zlog, zlog_stride, nullptr, nullptr, n_rays, n_samples, 0, 0.f, seg, weights, nullptr, nullptr, 0, 0);
+    });
     return nerf_launch_status("nerf_coarse_weights");
 }
 
@@ -989,9 +972,11 @@ int nerf_reweight(const float* weights, int64_t n_rays, int n_samples, float alp
     SegCfg seg = {};
     const char* err = nullptr;
     if (fill_segments(seg, steps, n_segments, n_samples, &err)) { nerf_set_error("nerf_reweight: %s", err); return NERF_EINVAL; }
-    ray_sampling_kernel<1><<<(unsigned)ceil_div64(n_rays, kRaysPerBlock), 256, 0, S_(stream)>>>(
-        weights, nullptr, 0, nullptr, nullptr, n_rays, n_samples, 0, (float)((double)alpha / (double)n_samples), seg, pdf,
-        nullptr, nullptr, 0, 0);
+    row_dispatch(row_shape(n_samples, 0, {weights, pdf}), [&](auto c_, auto v_) {
+        ray_sampling_kernel<1, ROW_C, ROW_V><<<(unsigned)ceil_div64(n_rays, kRaysPerBlock), 256, 0, S_(stream)>>>(
+            weights, nullptr, 0, nullptr, nullptr, n_rays, n_samples, 0, (float)((double)alpha / (double)n_samples), seg, pdf,
+            nullptr, nullptr, 0, 0);
+    });
     return nerf_launch_status("nerf_reweight");
 }
 
@@ -1003,8 +988,11 @@ int nerf_sample_pdf(const float* zlog, int64_t zlog_stride, const float* pdf, co
     NERF_REQUIRE(n_importance >= 1, "n_importance must be positive");
     if (n_rays <= 0) return n_rays == 0 ? 0 : NERF_EINVAL;
     SegCfg seg = {};
-    ray_sampling_kernel<2><<<(unsigned)ceil_div64(n_rays, kRaysPerBlock), 256, 0, S_(stream)>>>(
-        pdf, zlog, zlog_stride, noise, lin, n_rays, n_samples, n_importance, 0.f, seg, zlog_fine, z_fine, inds, 0, 0);
+    const size_t lds = (size_t)kRaysPerBlock * 2 * n_samples * sizeof(float);
+    row_dispatch(row_shape(n_samples, zlog_stride, {pdf, zlog}), [&](auto c_, auto v_) {
+        ray_sampling_kernel<2, ROW_C, ROW_V><<<(unsigned)ceil_div64(n_rays, kRaysPerBlock), 256, lds, S_(stream)>>>(
+            pdf, zlog, zlog_stride, noise, lin, n_rays, n_samples, n_importance, 0.f, seg, zlog_fine, z_fine, inds, 0, 0);
+    });
     return nerf_launch_status("nerf_sample_pdf");
 }
 
@@ -1018,9 +1006,12 @@ static int coarse_to_fine(const char* fn, const float* sigma, const float* zlog,
     SegCfg seg = {};
     const char* err = nullptr;
     if (fill_segments(seg, steps, n_segments, n_samples, &err)) { nerf_set_error("%s: %s", fn, err); return NERF_EINVAL; }
-    ray_sampling_kernel<3><<<(unsigned)ceil_div64(n_rays, kRaysPerBlock), 256, 0, S_(stream)>>>(
-        sigma, zlog, zlog_stride, noise, lin, n_rays, n_samples, n_importance, (float)((double)alpha / (double)n_samples), seg,
-        zlog_fine, z_fine, nullptr, seed, counter);
+    const size_t lds = (size_t)kRaysPerBlock * 2 * n_samples * sizeof(float);
+    row_dispatch(row_shape(n_samples, zlog_stride, {sigma, zlog}), [&](auto c_, auto v_) {
+        ray_sampling_kernel<3, ROW_C, ROW_V><<<(unsigned)ceil_div64(n_rays, kRaysPerBlock), 256, lds, S_(stream)>>>(
+            sigma, zlog, zlog_stride, noise, lin, n_rays, n_samples, n_importance,
+            (float)((double)alpha / (double)n_samples), seg, zlog_fine, z_fine, nullptr, seed, counter);
+    });
     return nerf_launch_status(fn);
 }
 
@@ -1053,8 +1044,10 @@ int nerf_composite_fwd(const float* sigma, const float* rgb, const float* z, con
     NERF_REQUIRE(sigma && rgb && z && zlog && bg && image && invdepth && weights, "null pointer");
     NERF_REQUIRE(check_ray_args(n_rays, n_samples) != 2, "n_samples must be in [1, 512]");
     if (n_rays <= 0) return n_rays == 0 ? 0 : NERF_EINVAL;
-    composite_fwd_kernel<<<(unsigned)ceil_div64(n_rays, kRaysPerBlock), 256, 0, S_(stream)>>>(
-        sigma, rgb, z, zlog, bg, n_rays, n_samples, zlog_lo, zlog_range, image, invdepth, weights, zlog_s);
+    row_dispatch(row_shape(n_samples, 0, {sigma, rgb, z, zlog, weights, zlog_s}), [&](auto c_, auto v_) {
+        composite_fwd_kernel<ROW_C, ROW_V><<<(unsigned)ceil_div64(n_rays, kRaysPerBlock), 256, 0, S_(stream)>>>(
+            sigma, rgb, z, zlog, bg, n_rays, n_samples, zlog_lo, zlog_range, image, invdepth, weights, zlog_s);
+    });
     return nerf_launch_status("nerf_composite_fwd");
 }
 
@@ -1063,8 +1056,10 @@ int nerf_composite_bwd(const float* sigma, const float* rgb, const float* zlog, 
     NERF_REQUIRE(sigma && rgb && zlog && bg && dimage && dsigma && drgb, "null pointer");
     NERF_REQUIRE(check_ray_args(n_rays, n_samples) != 2, "n_samples must be in [1, 512]");
     if (n_rays <= 0) return n_rays == 0 ? 0 : NERF_EINVAL;
-    composite_bwd_kernel<<<(unsigned)ceil_div64(n_rays, kRaysPerBlock), 256, 0, S_(stream)>>>(
-        sigma, rgb, zlog, bg, dimage, dweights, n_rays, n_samples, dsigma, drgb);
+    row_dispatch(row_shape(n_samples, 0, {sigma, rgb, zlog, dweights, dsigma, drgb}), [&](auto c_, auto v_) {
+        composite_bwd_kernel<ROW_C, ROW_V><<<(unsigned)ceil_div64(n_rays, kRaysPerBlock), 256, 0, S_(stream)>>>(
+            sigma, rgb, zlog, bg, dimage, dweights, n_rays, n_samples, dsigma, drgb);
+    });
     return nerf_launch_status("nerf_composite_bwd");
 }
 
@@ -1078,8 +1073,16 @@ int nerf_losses(const float* image, const float* gt, const float* weights, const
     zero_doubles_kernel<<<1, 64, 0, S_(stream)>>>(sums, 6);
     const int64_t loss_blocks = ceil_div64(n_rays, kRaysPerBlock);
     static const int loss_cap = getenv("NERF_LOSS_BLOCKS") ? atoi(getenv("NERF_LOSS_BLOCKS")) : kNumCU;
-    losses_kernel<<<(unsigned)(loss_blocks < loss_cap ? loss_blocks : loss_cap), 256, 0, S_(stream)>>>(
-        image, gt, weights, zlog_s, n_rays, n_samples, lam_dist, lam_depth, grad_scale, sorted, sums, dimage, dweights);
+    const unsigned n_wg = (unsigned)(loss_blocks < loss_cap ? loss_blocks : loss_cap);
+    if (weights && sorted) {
+        row_dispatch(row_shape(n_samples, 0, {weights, zlog_s, dweights}), [&](auto c_, auto v_) {
+            losses_sorted_kernel<ROW_C, ROW_V><<<n_wg, 256, 0, S_(stream)>>>(image, gt, weights, zlog_s, n_rays, n_samples, lam_dist,
+                                                                          lam_depth, grad_scale, sums, dimage, dweights);
+        });
+    } else {
+        losses_kernel<<<n_wg, 256, 0, S_(stream)>>>(image, gt, weights, zlog_s, n_rays, n_samples, lam_dist, lam_depth,
+                                                    grad_scale, sums, dimage, dweights);
+    }
     return nerf_launch_status("nerf_losses");
 }
 
@@ -1093,20 +1096,27 @@ int nerf_composite_loss_fwd(const float* sigma, const float* rgb, const float* z
     NERF_REQUIRE((((uintptr_t)sums) & 7) == 0, "sums must be 8-byte aligned");
     const int64_t blocks = ceil_div64(n_rays, kRaysPerBlock);
     const int n_wg = (int)(blocks < NERF_LOSS_MAX_ROWS ? blocks : NERF_LOSS_MAX_ROWS);
-    composite_loss_fwd_kernel<<<(unsigned)n_wg, 256, 0, S_(stream)>>>(sigma, rgb, z, zlog, bg, gt, n_rays, n_samples, zlog_lo,
-                                                                    zlog_range, image, invdepth, weights, zlog_s, sums + 8);
+    row_dispatch(row_shape(n_samples, 0, {sigma, rgb, z, zlog, weights, zlog_s}), [&](auto c_, auto v_) {
+        composite_loss_fwd_kernel<ROW_C, ROW_V><<<(unsigned)n_wg, 256, 0, S_(stream)>>>(
+            sigma, rgb, z, zlog, bg, gt, n_rays, n_samples, zlog_lo, zlog_range, image, invdepth, weights, zlog_s, sums + 8);
+    });
     composite_loss_finish_kernel<<<1, 256, 0, S_(stream)>>>(sums + 8, n_wg, lam_dist, lam_depth, sums, loss_out);
     return nerf_launch_status("nerf_composite_loss_fwd");
 }
 
 int nerf_composite_loss_bwd(const float* sigma, const float* rgb, const float* zlog, const float* bg, const float* gt,
                             const float* image, const float* dout, int64_t n_rays, int n_samples, float zlog_lo,
-                            float zlog_range, float lam_dist, float lam_depth, float* dsigma, float* drgb, void* stream) {
+                            float zlog_range, float lam_dist, float lam_depth, float* dsigma, float* drgb,
+                            double* nonfinite_flag, void* stream) {
     NERF_REQUIRE(sigma && rgb && zlog && bg && gt && image && dsigma && drgb, "null pointer");
+    NERF_REQUIRE((((uintptr_t)nonfinite_flag) & 7) == 0, "nonfinite_flag must be 8-byte aligned");
     NERF_REQUIRE(check_ray_args(n_rays, n_samples) != 2, "n_samples must be in [1, 512]");
     if (n_rays <= 0) return n_rays == 0 ? 0 : NERF_EINVAL;
-    composite_loss_bwd_kernel<<<(unsigned)ceil_div64(n_rays, kRaysPerBlock), 256, 0, S_(stream)>>>(
-        sigma, rgb, zlog, bg, gt, image, dout, n_rays, n_samples, zlog_lo, zlog_range, lam_dist, lam_depth, dsigma, drgb);
+    row_dispatch(row_shape(n_samples, 0, {sigma, rgb, zlog, dsigma, drgb}), [&](auto c_, auto v_) {
+        composite_loss_bwd_kernel<ROW_C, ROW_V><<<(unsigned)ceil_div64(n_rays, kRaysPerBlock), 256, 0, S_(stream)>>>(
+            sigma, rgb, zlog, bg, gt, image, dout, n_rays, n_samples, zlog_lo, zlog_range, lam_dist, lam_depth, dsigma, drgb,
+            nonfinite_flag);
+    });
     return nerf_launch_status("nerf_composite_loss_bwd");
 }
 
@@ -1114,7 +1124,10 @@ int nerf_cum_weights_thresh(const float* weights, int64_t n_rays, int n_samples,
     NERF_REQUIRE(weights && out, "null pointer");
     NERF_REQUIRE(check_ray_args(n_rays, n_samples) != 2, "n_samples must be in [1, 512]");
     if (n_rays <= 0) return n_rays == 0 ? 0 : NERF_EINVAL;
-    cum_thresh_kernel<<<(unsigned)ceil_div64(n_rays, kRaysPerBlock), 256, 0, S_(stream)>>>(weights, n_rays, n_samples, thresh, out);
+    row_dispatch(row_shape(n_samples, 0, {weights, out}), [&](auto c_, auto v_) {
+        cum_thresh_kernel<ROW_C, ROW_V><<<(unsigned)ceil_div64(n_rays, kRaysPerBlock), 256, 0, S_(stream)>>>(weights, n_rays,
+                                                                                                          n_samples, thresh, out);
+    });
     return nerf_launch_status("nerf_cum_weights_thresh");
 }
 

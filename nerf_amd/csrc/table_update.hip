@@ -244,7 +244,8 @@ __global__ __launch_bounds__(kBinThreads) void bin_fill_sorted_kernel(GridDev g,
     // From here on the barriers order LDS traffic only (s_waitcnt lgkmcnt(0) + s_barrier): nothing in global memory is
     // shared between the threads of this kernel, and a __syncthreads() would make every round wait until its scattered
     // item stores -- and the next round's point / gradient loads, requested a round ahead -- have completed.
-    auto lds_sync = [] { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_s_barrier(); };
+    // (asm with a "memory" clobber: the two builtins are IntrNoMem for LLVM, which could then move LDS accesses across them)
+    auto lds_sync = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     const LevelP lp = plan_level(g, l);
     const int col = plan.col[slot];
     uint16_t* ii = item_idx + plan.item_off[slot];
@@ -389,8 +390,9 @@ __global__ __launch_bounds__(kSplitThreads) void table_update_kernel(GridDev g, 
     }
 #pragma unroll
     for (int u = 0; u < kQuads; ++u) acc4[tid + u * T] = zero;
-    __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0) only: the loads above stay in flight across the barrier
-    __builtin_amdgcn_s_barrier();
+    // lgkmcnt(0) only: the loads above stay in flight across the barrier ("memory": a compiler-level fence for the LDS
+    // accesses on both sides, which the IntrNoMem builtins would not be)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const uint32_t* bs = bin_start + plan.part_base[slot] + slot;
     // (clamped: a workspace that was not filled for these levels / this point count must not turn into wild reads)
     const uint32_t n_items = (uint32_t)n_items_level;
@@ -445,8 +447,7 @@ __global__ __launch_bounds__(kSplitThreads) void table_update_kernel(GridDev g, 
     } else {
         for (int64_t i = i0 + tid; i < i1; i += T) add_item(i, item_idx[i]);
     }
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
     for (int u = 0; u < kQuads; ++u) {
         const int ii = tid + u * T;
@@ -572,8 +573,8 @@ int bin_passes(const char* fn, const NerfGridCfg* grid, const NerfPointSrc* src,
         }                                                                                                              \
         if (do_fill && sorted) {                                                                                       \
             auto kern = bin_fill_sorted_kernel<FF>;                                                                    \
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, sorted_lds); \
-            if (e != hipSuccess) { nerf_set_error("%s: LDS attribute: %s", fn, hipGetErrorString(e)); return (int)e; }  \
+            static NerfLdsAttrCache lds_cache = {};   /* per instantiation */    \
+            if (int e = nerf_ensure_dynamic_lds((const void*)kern, sorted_lds, &lds_cache, "table_bin_fill")) return e;    \
             kern<<<nbf, kBinThreads, sorted_lds, st>>>(g, *src, plan, M, chunk0, nb_max, hist, dfeat, dfeat_stride, item_idx, \
                                                        item_val);                                                      \
         } else if (do_fill) {                                                                                          \

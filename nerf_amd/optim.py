@@ -240,9 +240,12 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.grad_scale = 1.0
         self._cleared_at = None       # model.backward_count at the end of the last step() (attached models only)
-        # Non-finite guard: a one-element fp64 device tensor (helpers.fused_train_loss -> loss.nonfinite_flag); when it is
-        # non-zero the NEXT step() leaves parameters and moments untouched and only clears the gradients -- decided on
-        # the device, no host sync (GradScaler's role at trainer.py:134-136).  Consumed by one step().
+        # Non-finite guard: a one-element fp64 device tensor (helpers.fused_train_loss / NerfRenderer.render_loss ->
+        # loss.nonfinite_flag); when it is non-zero the NEXT step() leaves parameters and moments untouched and only clears
+        # the gradients -- decided on the device, no host sync (GradScaler's role at trainer.py:134-136).  Consumed by one
+        # step().  What raises it: a NaN / Inf loss (both routes) and, on the render_loss route, a NaN / Inf in the
+        # compositing gradients d(sigma), d(rgb) of a finite loss (nerf_composite_loss_bwd).  Underneath, every Adam kernel
+        # leaves an ENTRY whose own gradient is not finite untouched (adam_common.h), whatever the flag says.
         self.skip_flag = None
         self.skipped_steps = 0        # steps found dropped so far (read back lazily, see _collect_flags)
         self._flag_reads = []         # (event, pinned host copy) of the flags of earlier steps
@@ -310,23 +313,30 @@ class FusedAdam(torch.optim.Optimizer):
         (GradScaler does not call optimizer.step at all), so the step counters are taken back -- a few steps late, which
         only touches the bias-correction factor of those few steps, but without ever blocking the host."""
         keep = []
-        for ev, host in self._flag_reads:
+        for ev, host, stepped in self._flag_reads:
             if wait:
                 ev.synchronize()
             if ev.query():
                 if float(host[0]) != 0.0:
                     self.skipped_steps += 1
-                    for st in self.state.values():
+                    for p in stepped:       # only the parameters that took part in the dropped step
+                        st = self.state.get(p)
                         if st and st.get('step', 0) > 0:
                             st['step'] -= 1
             else:
-                keep.append((ev, host))
+                keep.append((ev, host, stepped))
         self._flag_reads = keep
+
+    def state_dict(self):
+        """(A checkpoint written right after a dropped step must not count it: the pending flags are read first.)"""
+        self._collect_flags(wait=True)
+        return super().state_dict()
 
     @torch.no_grad()
     def step(self, closure=None):
         flag = self.skip_flag
         self._skip_ptr = ptr(flag) if flag is not None else None
+        self._stepped = []
         if self._flag_reads:
             self._collect_flags()
         # One GPU with the binned table update: the small tensors (MLPs, latent table) take their Adam step on the side
@@ -356,7 +366,7 @@ class FusedAdam(torch.optim.Optimizer):
             host.copy_(flag, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
-            self._flag_reads.append((ev, host))
+            self._flag_reads.append((ev, host, self._stepped))
             self.skip_flag = None
 
     def _step_param(self, group, p):
@@ -373,6 +383,8 @@ class FusedAdam(torch.optim.Optimizer):
             # first Adam pass and wipe its moments (v = 0 with m != 0 then divides by eps on the next step).
             torch.cuda.current_stream().synchronize()
         st['step'] += 1
+        if getattr(self, '_stepped', None) is not None:
+            self._stepped.append(p)
         pipe = self._pipeline
         if p is self._table_param and pipe is not None and pipe.binned_levels:
             self._binned_table_step(p, st, group, b1, b2, pipe)
@@ -404,6 +416,7 @@ class FusedAdam(torch.optim.Optimizer):
     def sync_sharded_state(self):
         """Level-sharded table: collect the Adam moments of every level from its owner (collective; needed before
         the optimizer state is saved, so that a checkpoint can be resumed with any number of ranks)."""
+        self._collect_flags(wait=True)
         if self._sharding is not None and self._table_param in self.state and self.state[self._table_param]:
             st = self.state[self._table_param]
             self._sharding.sync_levels(st['exp_avg'])

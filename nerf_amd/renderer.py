@@ -75,9 +75,9 @@ class _CompositeLossFn(torch.autograd.Function):
         check(lib().nerf_composite_loss_fwd(ptr(sig), ptr(rgb), ptr(z), ptr(zl), ptr(bgc), ptr(g), N, S, lo, rng, lam_dist,
                                             lam_depth, ptr(image), ptr(invdepth), ptr(weights), ptr(zlog_s), ptr(sums),
                                             ptr(out), stream()), 'nerf_composite_loss_fwd')
-        ctx.save_for_backward(sig, rgb, zl, bgc, g, image)
-        ctx.consts = (lo, rng, lam_dist, lam_depth)
         loss, parts, flag = out[4], out[:4], sums[5:6]
+        ctx.save_for_backward(sig, rgb, zl, bgc, g, image, flag)
+        ctx.consts = (lo, rng, lam_dist, lam_depth)
         ctx.mark_non_differentiable(parts, flag, image, invdepth, weights, zlog_s)
         ctx.set_materialize_grads(False)
         return loss, parts, flag, image, invdepth, weights, zlog_s
@@ -86,13 +86,14 @@ class _CompositeLossFn(torch.autograd.Function):
     def backward(ctx, dout, *_unused):
         if dout is None:
             return (None,) * 10
-        sig, rgb, zl, bgc, g, image = ctx.saved_tensors
+        sig, rgb, zl, bgc, g, image, flag = ctx.saved_tensors
         lo, rng, lam_dist, lam_depth = ctx.consts
         N, S = sig.shape
         dsig = torch.empty_like(sig)
         drgb = torch.empty_like(rgb)
+        # (the flag: a finite loss whose gradients are not -- an Inf upstream gradient, an overflow -- drops the step too)
         check(lib().nerf_composite_loss_bwd(ptr(sig), ptr(rgb), ptr(zl), ptr(bgc), ptr(g), ptr(image), ptr(f32(dout)), N, S,
-                                            lo, rng, lam_dist, lam_depth, ptr(dsig), ptr(drgb), stream()),
+                                            lo, rng, lam_dist, lam_depth, ptr(dsig), ptr(drgb), flag.data_ptr(), stream()),
               'nerf_composite_loss_bwd')
         return (dsig, drgb) + (None,) * 8
 

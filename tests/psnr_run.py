@@ -123,8 +123,10 @@ def quality_run(res, n_img, L, T, iters, n_rays):
             'trained_render_rays_per_s_%dx%d_views' % (res, res): render_rps}
 
 
-def delta_run(res, n_img, L, T, iters, n_rays):
-    """HIP vs CPU oracle: identical init, batches, noise, budget."""
+def delta_run(res, n_img, L, T, iters, n_rays, fused_tail=True):
+    """HIP vs CPU oracle: identical init, batches, noise, budget.  `fused_tail`: the HIP side takes the route
+    Trainer.train_step takes (NerfRenderer.render_loss: compositing + losses in one kernel); False = render() followed by
+    helpers.fused_train_loss.  The result names the table levels that went through the binned update."""
     loader = ProceduralSceneLoader(n_img, res, res, seed=0, batch_seed=1)
     imgs = render_ground_truth(loader, res)
     loader.set_images(imgs)
@@ -156,8 +158,12 @@ def delta_run(res, n_img, L, T, iters, n_rays):
         oo.step()
         og.zero_grad()
         c = lambda t: t.cuda()
-        img, wts, zs, _ = Rg.render(c(n), c(h), c(w), c(K_all[n]), c(E_all[n]), c(bg), noise=c(noise))
-        loss_g, _ = helpers.fused_train_loss(img, c(gt), wts, zs, lam, 0.1)
+        if fused_tail:
+            loss_g = Rg.render_loss(c(n), c(h), c(w), c(K_all[n]), c(E_all[n]), c(bg), c(gt), lam, 0.1, noise=c(noise))[0]
+        else:
+            img, wts, zs, _ = Rg.render(c(n), c(h), c(w), c(K_all[n]), c(E_all[n]), c(bg), noise=c(noise))
+            loss_g, _ = helpers.fused_train_loss(img, c(gt), wts, zs, lam, 0.1)
+        og.skip_flag = loss_g.nonfinite_flag
         loss_g.backward()
         og.step()
         lo.append(float(loss_o))
@@ -173,8 +179,10 @@ def delta_run(res, n_img, L, T, iters, n_rays):
     gtc = gt.reshape(-1, 3)
     p_o = ref_cpu.psnr(img_o.clamp(0, 1), gtc.cpu())
     p_g = helpers.psnr(img_g.detach().clamp(0, 1), gtc)
+    pipe = net.table_pipeline
     return {'config': 'L%d T%d, %d images %dx%d, %d iters x %d rays, identical init/batches/noise' % (L, T, n_img, res, res, iters, n_rays),
-            'psnr_hip': p_g, 'psnr_cpu_oracle': p_o, 'psnr_delta': p_g - p_o,
+            'binned_levels': list(pipe.binned_levels) if pipe is not None else [], 'fused_tail': bool(fused_tail),
+            'skipped_steps': og.skipped_steps, 'psnr_hip': p_g, 'psnr_cpu_oracle': p_o, 'psnr_delta': p_g - p_o,
             'max_abs_loss_diff': max(abs(a - b) for a, b in zip(lg, lo)), 'loss_first': [lg[0], lo[0]], 'loss_last': [lg[-1], lo[-1]],
             'max_abs_image_diff': float((img_g.detach().cpu() - img_o).abs().max())}
 
@@ -184,11 +192,20 @@ if __name__ == '__main__':
     ap.add_argument('--out', default=os.path.join(ROOT, 'profiles', 'psnr_r01.json'))
     ap.add_argument('--quality-iters', type=int, default=2000)
     ap.add_argument('--delta-iters', type=int, default=60)
+    ap.add_argument('--metric-delta-iters', type=int, default=60,
+                    help='PSNR delta at the METRIC network (L20 T24, 4096 rays): the oracle takes ~2.5 s per step')
+    ap.add_argument('--build', default='', help='commit / label of the build that produced the file')
     args = ap.parse_args()
-    out = {}
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    out = {'build': args.build}
     out['quality_full'] = quality_run(res=200, n_img=100, L=20, T=24, iters=args.quality_iters, n_rays=4096)
     print(json.dumps(out['quality_full']), flush=True)
     out['delta_small'] = delta_run(res=64, n_img=20, L=8, T=15, iters=args.delta_iters, n_rays=1024)
     print(json.dumps(out['delta_small']), flush=True)
+    out['delta_binned_T19'] = delta_run(res=64, n_img=20, L=20, T=19, iters=40, n_rays=1024)
+    print(json.dumps(out['delta_binned_T19']), flush=True)
+    if args.metric_delta_iters > 0:
+        out['delta_metric_network'] = delta_run(res=200, n_img=100, L=20, T=24, iters=args.metric_delta_iters, n_rays=4096)
+        print(json.dumps(out['delta_metric_network']), flush=True)
     with open(args.out, 'w') as f:
         json.dump(out, f, indent=1)

@@ -277,12 +277,16 @@ def test_train_steps_vs_oracle(name, binned, monkeypatch):
     assert bool(net.table_pipeline.binned_levels) == (name == 'base19' and binned == '1')
     lo, lg = [], []
     n_steps = 20 if (name, binned) in (('small', '1'), ('base19', '1')) else 4      # a 20-step trace
+    w0 = ora.sigma_params.detach().clone()
+    steady = torch.ones_like(w0, dtype=torch.bool)     # weights whose oracle gradient is above summation noise at EVERY step
     for it in range(n_steps):
         n, h, w, K, E, bg, noise, gt = _batch(10 + it, 96)
         oo.zero_grad()
         img, wts, zs, _ = Ro.render(n, h, w, K, E, bg, noise=noise)
         loss, _ = ref_cpu.train_loss(img, gt, wts, zs, it, 100, 1e-5, 1e-2, 1e-1, 1e-1)
         loss.backward()
+        g_o = ora.sigma_params.grad.detach()
+        steady &= g_o.abs() > 1e-2 * float(g_o.abs().max())
         oo.step()
         lo.append(float(loss))
         og.zero_grad()
@@ -309,9 +313,20 @@ def test_train_steps_vs_oracle(name, binned, monkeypatch):
     # near-zero gradients into +-lr parameter steps), so the bar widens with the step count
     for k, (a, b) in enumerate(zip(lg, lo)):
         assert abs(a - b) <= (2e-4 if k < 4 else 2e-3) * max(1.0, abs(b)), (k, lg, lo)
-    # (lr 1e-3 x 4 steps: a weight whose tiny gradient flips sign with the summation order moves by up to 2 lr per step)
-    torch.testing.assert_close(net.sigma_net.params.detach().cpu(), ora.sigma_params.detach(), rtol=0,
-                               atol=(3e-3 if name == 'base19' else 2e-3) * (n_steps / 4))
+    # Weights.  Adam with eps = 1e-15 moves EVERY weight by about lr per step whatever the size of its gradient, so a weight
+    # whose gradient is summation noise (|g| << max |g|: its sign depends on the order of the sum) can differ by up to
+    # 2 lr per step and says nothing about parity.  The bar is therefore set on the weights whose oracle gradient stayed
+    # above 1 % of the largest one at every step -- they moved by ~n_steps * lr = 4e-3 .. 2e-2 and must agree to a small
+    # fraction of that -- and on the distribution of all of them.
+    wg, wo = net.sigma_net.params.detach().cpu(), ora.sigma_params.detach()
+    diff = (wg - wo).abs()
+    moved = (wo - w0).abs()
+    assert int(steady.sum()) >= 50, int(steady.sum())
+    assert float(moved[steady].median()) > 0.5e-3 * n_steps, float(moved[steady].median())
+    stats = (name, binned, n_steps, int(steady.sum()), float(diff[steady].max()), float(diff.median()), float(diff.max()))
+    assert float(diff[steady].max()) <= 0.1e-3 * n_steps, stats          # <= 10 % of the distance they travelled
+    assert float(diff.median()) <= 0.05e-3 * n_steps, stats
+    assert float(diff.max()) <= 2.2e-3 * n_steps, stats                  # nothing moved further than Adam can move it
     # Adam invariants of the table: a parameter that ever saw a gradient has both moments, and the moments agree with
     # the oracle's (torch.optim.Adam) wherever they are not summation noise.  (The first pipelined step once lost its
     # moments to a late zero-fill: v = 0 under m != 0 divides by eps on the next step.)
