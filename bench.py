@@ -174,7 +174,7 @@ def per_ray_kernels_at(n_rays=65536, Sc=64, Sf=SF, reps=20):
     wts, zs = torch.empty(N, Sf, device=dev), torch.empty(N, Sf, device=dev)
     dsig, drgb = torch.empty(N, Sf, device=dev), torch.empty(N, Sf, 3, device=dev)
     dimg, dw = torch.rand(N, 3, device=dev, generator=g), torch.rand(N, Sf, device=dev, generator=g)
-    sums = torch.empty(8 + 4 * 1024, device=dev, dtype=torch.float64)
+    sums = torch.empty(8 + 4 * 4096, device=dev, dtype=torch.float64)
     out6 = torch.empty(6, device=dev)
     lo, rng = math.log10(1.6), math.log10(4.8) - math.log10(1.6)
     L = lib()

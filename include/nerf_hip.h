@@ -273,7 +273,7 @@ int nerf_losses(const float* image, const float* gt, const float* weights, const
  * [8 ..] one row of four partial sums per workgroup (added up in a fixed order: the totals are reproducible run to run).
  * loss_out: six floats: loss_rgb, loss_dist, loss_depth, mse, the total and the flag.
  * dout (nullable = 1): device scalar, d(objective)/d(total loss) -- what autograd hands to backward(). */
-#define NERF_LOSS_MAX_ROWS 1024
+#define NERF_LOSS_MAX_ROWS 4096
 #define NERF_LOSS_SUMS_DOUBLES (8 + 4 * NERF_LOSS_MAX_ROWS)
 int nerf_composite_loss_fwd(const float* sigma, const float* rgb, const float* z, const float* zlog, const float* bg,
                             const float* gt /*[N,3]*/, int64_t n_rays, int n_samples, float zlog_lo, float zlog_range,

@@ -70,7 +70,7 @@ class _CompositeLossFn(torch.autograd.Function):
         invdepth = torch.empty(N, device=dev)
         weights = torch.empty(N, S, device=dev)
         zlog_s = torch.empty(N, S, device=dev)
-        sums = torch.empty(8 + 4 * 1024, device=dev, dtype=torch.float64)     # NERF_LOSS_SUMS_DOUBLES
+        sums = torch.empty(8 + 4 * 4096, device=dev, dtype=torch.float64)     # NERF_LOSS_SUMS_DOUBLES
         out = torch.empty(6, device=dev)
         check(lib().nerf_composite_loss_fwd(ptr(sig), ptr(rgb), ptr(z), ptr(zl), ptr(bgc), ptr(g), N, S, lo, rng, lam_dist,
                                             lam_depth, ptr(image), ptr(invdepth), ptr(weights), ptr(zlog_s), ptr(sums),

@@ -231,3 +231,64 @@ def test_full_image_inference_is_independent_of_the_traversal(scene):
     finally:
         inference_mod.COHERENT_RAYS = old
     assert np.array_equal(img0, img1) and np.array_equal(inv0, inv1)
+
+
+def test_dense_extraction_at_full_size(scene):
+    """BASELINE config 5 (allign/extract_dense_geometry.py:58-101, allign/config.yaml:21-24): 512^3 voxel centres, 128^3
+    camera mask from the procedural cameras, batches of 524 288.  Properties: the number of points equals the number of
+    valid voxels over the threshold counted by a second, plain pass (canonical voxel order, plain torch masking and
+    thresholding around the field call); the points come in ascending voxel order; the result is bit-identical without
+    the 4 x 4 x 2 brick order and under another batch size."""
+    import nerf_amd.extract_dense_geometry as edg
+    from nerf_amd.loaders.procedural import ProceduralSceneLoader
+    net, _, _ = scene
+    loader = ProceduralSceneLoader(100, 800, 800, seed=0)
+    N, H, W, K, E = loader.get_calibration()
+    Rv, Rm = 512, 128
+    ex = edg.ExtractDenseGeometry(net, loader, Rm, Rv, 524288, 0.0, 2.5)
+    mask = ex.get_valid_positions(N, H, W, K, E, res=Rm)
+    frac = float(mask.float().mean())
+    assert 0.05 < frac < 0.6, frac                   # inside the unit sphere (0.52 of the cube) and seen by a camera
+    # ---- second pass: every voxel in canonical order, slab by slab, plain torch around the field call ----
+    vox = torch.linspace(-1 + 1 / Rv, 1 - 1 / Rv, Rv).cuda()
+    mi = ((vox + 1) / 2 * Rm).to(torch.int64)
+    sig_valid = []
+    idx_valid = []
+    for x0 in range(0, Rv, 16):
+        n = torch.arange(x0 * Rv * Rv, (x0 + 16) * Rv * Rv, device='cuda')
+        ix, iy, iz = torch.div(n, Rv * Rv, rounding_mode='floor'), torch.div(n, Rv, rounding_mode='floor') % Rv, n % Rv
+        ok = mask[mi[ix], mi[iy], mi[iz]]
+        n = n[ok]
+        xyz = torch.stack((vox[ix[ok]], vox[iy[ok]], vox[iz[ok]]), -1).contiguous()
+        if n.numel() == 0:
+            continue
+        d = torch.tensor([0.0, 0.0, 1.0], device='cuda').expand(n.numel(), 3).contiguous()
+        sg, _ = net.field_nograd(dict(outer_bound=2.5, x=xyz, d=d, n=torch.zeros(n.numel(), dtype=torch.int64, device='cuda'),
+                                      n_points=n.numel()))
+        sig_valid.append(sg.clone())
+        idx_valid.append(n)
+    sig_valid, idx_valid = torch.cat(sig_valid), torch.cat(idx_valid)
+    assert abs(idx_valid.numel() / Rv ** 3 - frac) < 0.02
+    thresh = float(sig_valid.float().kthvalue(int(0.995 * sig_valid.numel())).values)      # ~0.5 % of the valid voxels pass
+    want_idx = idx_valid[sig_valid > thresh]
+    assert want_idx.numel() > 10000
+    del sig_valid, idx_valid
+    # ---- the extraction proper ----
+    ex.thresh = thresh
+    pts, col = ex.extract_dense_geometry(N, H, W, K, E, mask=mask)
+    assert pts.shape == (want_idx.numel(), 3) and col.shape == pts.shape
+    voxc = vox.cpu()
+    want_pts = torch.stack((voxc[torch.div(want_idx.cpu(), Rv * Rv, rounding_mode='floor')],
+                            voxc[torch.div(want_idx.cpu(), Rv, rounding_mode='floor') % Rv], voxc[want_idx.cpu() % Rv]), -1)
+    assert torch.equal(pts, want_pts)                # the same voxels, in ascending voxel order
+    assert bool(torch.isfinite(col).all()) and float(col.min()) >= 0 and float(col.max()) <= 1
+    old = edg.BRICK_ORDER
+    edg.BRICK_ORDER = False
+    try:
+        pts_l, col_l = ex.extract_dense_geometry(N, H, W, K, E, mask=mask)
+    finally:
+        edg.BRICK_ORDER = old
+    assert torch.equal(pts_l, pts) and torch.equal(col_l, col)
+    ex.batch_size = 1000003
+    pts_b, col_b = ex.extract_dense_geometry(N, H, W, K, E, mask=mask)
+    assert torch.equal(pts_b, pts) and torch.equal(col_b, col)

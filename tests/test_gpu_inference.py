@@ -195,6 +195,13 @@ def _infer_everything(world):
     ex.thresh = 0.05
     pts, col = ex.extract_dense_geometry(N_, H_, W_, Kc, Ec, mask=torch.ones(4, 4, 4, dtype=torch.bool, device='cuda'))
     out['dense_points'], out['dense_colors'] = pts.numpy(), col.numpy()
+    # a slab run at 128^3 with the camera mask (32^3): 2 M voxels, 8 slabs of batches per rank
+    ex128 = ExtractDenseGeometry(net, loader, 32, 128, 65536, 0.0, 2.5)
+    mask128 = ex128.get_valid_positions(N_, H_, W_, Kc, Ec, res=32)
+    out['mask128_kept'] = np.array([int(mask128.sum())])
+    ex128.thresh = 0.05
+    pts, col = ex128.extract_dense_geometry(N_, H_, W_, Kc, Ec, mask=mask128)
+    out['dense128_points'], out['dense128_colors'] = pts.numpy(), col.numpy()
     torch.cuda.synchronize()
     return out
 
@@ -229,6 +236,7 @@ def test_sharded_inference_and_extraction_match_single_process():
     assert all(p.exitcode == 0 for p in procs)
     want = _infer_everything(1)
     assert want['points'].shape[0] > 20 and want['dense_points'].shape[0] > 100 and float(want['invdepth_thresh'].max()) > 0
+    assert want['mask128_kept'][0] > 1000 and want['dense128_points'].shape[0] > 1000, (want['mask128_kept'], want['dense128_points'].shape)
     for r in range(world):
         for k, v in want.items():
             assert got[r][k].shape == v.shape, (r, k, got[r][k].shape, v.shape)
