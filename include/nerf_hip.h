@@ -150,7 +150,10 @@ int nerf_mlp_bwd(const float* params, const int32_t* dims, int n_layers, const f
  * until the process ends); the call allocates and frees nothing.  n_rows is limited by that array: the floats
  * nerf_mlp_bwd_workspace_floats reports must not exceed 4 718 592 (9162 rows for 79 -> 64 -> 64 -> 3), else
  * NERF_EINVAL with a message naming the limit.  All calls on one GPU share the array: calls that overlap on one GPU
- * (two streams, two threads) race.  Same results as nerf_mlp_bwd. */
+ * (two streams, two threads) race.  Same results as nerf_mlp_bwd.
+ * The FIRST call on a device looks the array's address up (hipGetSymbolAddress, which may load the code object): that is
+ * not stream-ordered and must not run inside a graph capture.  Make one warm-up call per device outside any capture;
+ * n_rows = 0 (pointers may then be NULL) resolves the address and launches nothing. */
 int nerf_mlp_bwd_noalloc(const float* params, const int32_t* dims, int n_layers, const float* x, const float* dout,
                          int64_t n_rows, float* dx, float* dparams, void* stream);
 

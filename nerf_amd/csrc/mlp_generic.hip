@@ -166,9 +166,14 @@ extern "C" int nerf_mlp_bwd_noalloc(const float* params, const int32_t* dims, in
     }
     int dev = -1;
     hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+    if (e != hipSuccess) {
         nerf_set_error("nerf_mlp_bwd_noalloc: hipGetDevice: %s", hipGetErrorString(e));
-        return e != hipSuccess ? (int)e : NERF_EINVAL;
+        return (int)e;
+    }
+    if (dev < 0 || dev >= kMaxDevices) {
+        nerf_set_error("nerf_mlp_bwd_noalloc: device index %d is outside the %d devices this entry point keeps a buffer "
+                       "address for", dev, kMaxDevices);
+        return NERF_EINVAL;
     }
     float* ws = __atomic_load_n(&g_scratch_ptr[dev], __ATOMIC_ACQUIRE);
     if (!ws) {      // first call on this device (it is the current one): this device's copy of the array
@@ -179,6 +184,10 @@ extern "C" int nerf_mlp_bwd_noalloc(const float* params, const int32_t* dims, in
         }
         __atomic_store_n(&g_scratch_ptr[dev], ws, __ATOMIC_RELEASE);
     }
+    // The look-up above (and the lazy load of the code object behind it) is not stream-ordered and must not happen under
+    // a HIP graph capture: a caller that captures makes ONE call per device beforehand -- n_rows = 0 is enough (pointers
+    // may be NULL), it resolves the address and launches nothing.
+    if (n_rows == 0) return 0;
     // (nothing in the workspace has to start at zero: the forward pass rewrites every activation, every layer rewrites dz
     // and the gradient ping-pong buffers before reading them)
     return nerf_mlp_bwd(params, dims, n_layers, x, dout, n_rows, dx, dparams, ws, kScratchFloats, stream);
