@@ -224,6 +224,14 @@ __device__ __forceinline__ Corners level_corners(const LevelP& lp, float x, floa
         const uint32_t cx = ix + (k & 1), cy = iy + ((k >> 1) & 1), cz = iz + ((k >> 2) & 1);
         c.w[k] = __fmul_rn(__fmul_rn(ax[k & 1], ay[(k >> 1) & 1]), az[(k >> 2) & 1]);
         uint32_t dense = cx + cy * lp.res + cz * (lp.res * lp.res);
+#if defined(NERF_BRICK_PROBE)
+        // TIMING PROBE ONLY (tools/ab builds, never shipped: not a bijection at the level's edges): the big dense levels
+        // addressed in 4 x 4 x 4 bricks, to measure what a brick-ordered table layout would save in the forward gathers
+        if (!lp.hashed && lp.entries > (1u << 20)) {
+            const uint32_t nbr = (lp.res + 3u) >> 2;
+            dense = ((((cz >> 2) * nbr + (cy >> 2)) * nbr + (cx >> 2)) << 6) | ((cz & 3u) << 4) | ((cy & 3u) << 2) | (cx & 3u);
+        }
+#endif
         if (dense >= lp.entries) dense %= lp.entries;
         const uint32_t hash = (cx ^ (cy * 2654435761u) ^ (cz * 805459861u)) & (lp.entries - 1u);
         c.idx[k] = lp.offset + (lp.hashed ? hash : dense);

@@ -29,4 +29,19 @@ __device__ __forceinline__ float philox_uniform(uint64_t seed, uint64_t counter,
     return u01(w);
 }
 
+// elements e and e + 1 of the same stream: one Philox block when both lie in it (e even), else two
+__device__ __forceinline__ void philox_uniform2(uint64_t seed, uint64_t counter, uint64_t e, float& a, float& b) {
+    if ((e & 1) == 0) {
+        const uint64_t blk = e >> 2;
+        const U4 r = philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)counter, (uint32_t)(counter >> 32),
+                                   (uint32_t)seed, (uint32_t)(seed >> 32));
+        const bool upper = (e & 2) != 0;
+        a = u01(upper ? r.z : r.x);
+        b = u01(upper ? r.w : r.y);
+    } else {
+        a = philox_uniform(seed, counter, e);
+        b = philox_uniform(seed, counter, e + 1);
+    }
+}
+
 }  // namespace

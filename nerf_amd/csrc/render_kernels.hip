@@ -25,47 +25,68 @@ constexpr int kRaysPerBlock = 4;  // 256 threads, one wavefront per ray
 constexpr int kMaxS = NERF_MAX_SAMPLES;
 
 // ------------------------------------------------------------------------------------------
-// wavefront scans (fp64)
+// wavefront scans (fp64) on DPP: row shifts inside the 16-lane rows, then the two row broadcasts of GFX9 (lane 15 of a
+// row into the next row, lane 31 into rows 2 and 3).  Plain VALU moves: a __shfl_up ladder is six ds_bpermute round
+// trips through the LDS crossbar per scan, and these kernels are a chain of such scans.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_excl_prod(double v, int lane) {
-    double incl = v;
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        double o = __shfl_up(incl, off, kWave);
-        if (lane >= off) incl *= o;
-    }
-    double e = __shfl_up(incl, 1, kWave);
-    return lane == 0 ? 1.0 : e;
+// every lane: the value of the lane the DPP control names, `old` where that lane does not exist or the row is masked
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double old, double v) {
+    const uint64_t o = __builtin_bit_cast(uint64_t, old), s = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)o, (int)(uint32_t)s, CTRL, ROW_MASK, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(o >> 32), (int)(uint32_t)(s >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
 }
 
-__device__ __forceinline__ double wave_excl_sum(double v, int lane) {
-    double incl = v;
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        double o = __shfl_up(incl, off, kWave);
-        if (lane >= off) incl += o;
-    }
-    double e = __shfl_up(incl, 1, kWave);
-    return lane == 0 ? 0.0 : e;
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL,
+                                                                 0xf, 0xf, false));
 }
 
-// exclusive sum over the lanes ABOVE this one (suffix)
-__device__ __forceinline__ double wave_excl_suffix_sum(double v, int lane) {
-    double incl = v;
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        double o = __shfl_down(incl, off, kWave);
-        if (lane + off < kWave) incl += o;
-    }
-    double e = __shfl_down(incl, 1, kWave);
-    return lane == kWave - 1 ? 0.0 : e;
-}
+constexpr int kRowShr1 = 0x111, kRowShr2 = 0x112, kRowShr4 = 0x114, kRowShr8 = 0x118;
+constexpr int kRowBcast15 = 0x142, kRowBcast31 = 0x143, kWaveShl1 = 0x130, kWaveShr1 = 0x138;
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+__device__ __forceinline__ double wave_incl_sum(double v) {
+    v += dpp_f64<kRowShr1, 0xf>(0.0, v);
+    v += dpp_f64<kRowShr2, 0xf>(0.0, v);
+    v += dpp_f64<kRowShr4, 0xf>(0.0, v);
+    v += dpp_f64<kRowShr8, 0xf>(0.0, v);
+    v += dpp_f64<kRowBcast15, 0xa>(0.0, v);
+    v += dpp_f64<kRowBcast31, 0xc>(0.0, v);
     return v;
 }
+
+__device__ __forceinline__ double wave_incl_prod(double v) {
+    v *= dpp_f64<kRowShr1, 0xf>(1.0, v);
+    v *= dpp_f64<kRowShr2, 0xf>(1.0, v);
+    v *= dpp_f64<kRowShr4, 0xf>(1.0, v);
+    v *= dpp_f64<kRowShr8, 0xf>(1.0, v);
+    v *= dpp_f64<kRowBcast15, 0xa>(1.0, v);
+    v *= dpp_f64<kRowBcast31, 0xc>(1.0, v);
+    return v;
+}
+
+__device__ __forceinline__ double lane63(double v) {
+    const uint64_t s = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)s, 63);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(s >> 32), 63);
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+
+__device__ __forceinline__ double wave_excl_prod(double v, int) { return dpp_f64<kWaveShr1, 0xf>(1.0, wave_incl_prod(v)); }
+__device__ __forceinline__ double wave_excl_sum(double v, int) { return dpp_f64<kWaveShr1, 0xf>(0.0, wave_incl_sum(v)); }
+__device__ __forceinline__ double wave_sum(double v) { return lane63(wave_incl_sum(v)); }
+
+// exclusive sum over the lanes ABOVE this one (suffix) = total - inclusive prefix
+__device__ __forceinline__ double wave_excl_suffix_sum(double v, int) {
+    const double incl = wave_incl_sum(v);
+    return lane63(incl) - incl;
+}
+
+// the value of the next / previous lane (`edge` for lane 63 / lane 0)
+__device__ __forceinline__ float next_lane(float v, float edge) { return dpp_f32<kWaveShl1>(edge, v); }
+__device__ __forceinline__ float prev_lane(float v, float edge) { return dpp_f32<kWaveShr1>(edge, v); }
 
 // ------------------------------------------------------------------------------------------
 // R1: ray generation (renderer.py:38-48).  One thread per ray.
@@ -229,7 +250,7 @@ struct Trans {
 
 template <int C>
 __device__ __forceinline__ void transmittance(Trans<C>& t, const float (&sig)[C], const float (&zl)[C], int S, int lane) {
-    const float zl_next_lane = __shfl_down(zl[0], 1, kWave);
+    const float zl_next_lane = next_lane(zl[0], zl[0]);
     double prod = 1.0;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
@@ -255,9 +276,8 @@ __device__ __forceinline__ void transmittance(Trans<C>& t, const float (&sig)[C]
 template <int C>
 __device__ __forceinline__ void stage_reweight(const float (&w)[C], float (&pdf)[C], int S, int lane, float alpha_over_s,
                                                const SegCfg& seg) {
-    float w_prev_lane = __shfl_up(w[C - 1], 1, kWave);
-    if (lane == 0) w_prev_lane = 0.f;                           // the zero padding of :133
-    const float w_next_lane = __shfl_down(w[0], 1, kWave);
+    const float w_prev_lane = prev_lane(w[C - 1], 0.f);        // lane 0: the zero padding of :133
+    const float w_next_lane = next_lane(w[0], 0.f);
     float v[C];
     double local = 0.0;
 #pragma unroll
@@ -288,7 +308,7 @@ template <int C, class NoiseFn>
 __device__ __forceinline__ void stage_sample_pdf(const float (&pdf)[C], const float (&zl)[C], float* cdf_s, float* zl_s, int S,
                                                  int lane, NoiseFn noise, const float* __restrict__ lin, int Sf,
                                                  float* __restrict__ zlog_f, float* __restrict__ z_f,
-                                                 int64_t* __restrict__ inds) {
+                                                 int64_t* __restrict__ inds, bool pair_stores) {
     double local = 0.0;
 #pragma unroll
     for (int c = 0; c < C; ++c) local += (double)pdf[c];
@@ -303,23 +323,41 @@ __device__ __forceinline__ void stage_sample_pdf(const float (&pdf)[C], const fl
     const float* cdf = cdf_s;
     const float c1 = cdf[1], range = cdf[S - 2] - c1, fSf = (float)Sf;
     const int n_knots = S - 3;  // cdf[1 .. S-3]
-    for (int k = lane; k < Sf; k += kWave) {
-        float u = lin[k] + noise(k) / fSf;
-        u = u * range;
-        u = u + c1;
-        int lo = 0, hi = n_knots;
-        while (lo < hi) {  // searchsorted(..., right=True): first knot strictly greater than u
-            int mid = (lo + hi) >> 1;
-            if (cdf[1 + mid] <= u) lo = mid + 1; else hi = mid;
+    // a lane takes the fine samples 2 lane, 2 lane + 1 (+ 128, ...): two neighbours share one Philox block and leave as
+    // one 8-byte store
+    for (int k0 = 2 * lane; k0 < Sf; k0 += 2 * kWave) {
+        float nz[2];
+        noise(k0, nz);
+        float zf[2];
+        int idx[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = k0 + j < Sf ? k0 + j : k0;
+            float u = lin[k] + nz[j] / fSf;
+            u = u * range;
+            u = u + c1;
+            int lo = 0, hi = n_knots;
+            while (lo < hi) {  // searchsorted(..., right=True): first knot strictly greater than u
+                int mid = (lo + hi) >> 1;
+                if (cdf[1 + mid] <= u) lo = mid + 1; else hi = mid;
+            }
+            idx[j] = lo + 1;
+            float below = cdf[idx[j] - 1], above = cdf[idx[j]];
+            float t = (u - below) / (above - below);
+            float mb = (zl_s[idx[j] - 1] + zl_s[idx[j]]) / 2.f, ma = (zl_s[idx[j]] + zl_s[idx[j] + 1]) / 2.f;
+            zf[j] = mb + (ma - mb) * t;
         }
-        int idx = lo + 1;
-        float below = cdf[idx - 1], above = cdf[idx];
-        float t = (u - below) / (above - below);
-        float mb = (zl_s[idx - 1] + zl_s[idx]) / 2.f, ma = (zl_s[idx] + zl_s[idx + 1]) / 2.f;
-        float zf = mb + (ma - mb) * t;
-        zlog_f[k] = zf;
-        if (z_f) z_f[k] = powf(10.f, zf);
-        if (inds) inds[k] = idx;
+        const bool two = k0 + 1 < Sf;
+        if (two && pair_stores) {
+            vf2 a = {zf[0], zf[1]};
+            *(vf2*)(zlog_f + k0) = a;
+            if (z_f) { vf2 b = {powf(10.f, zf[0]), powf(10.f, zf[1])}; *(vf2*)(z_f + k0) = b; }
+        } else {
+            zlog_f[k0] = zf[0];
+            if (z_f) z_f[k0] = powf(10.f, zf[0]);
+            if (two) { zlog_f[k0 + 1] = zf[1]; if (z_f) z_f[k0 + 1] = powf(10.f, zf[1]); }
+        }
+        if (inds) { inds[k0] = idx[0]; if (two) inds[k0 + 1] = idx[1]; }
     }
 }
 
@@ -362,14 +400,18 @@ __global__ __launch_bounds__(256) void ray_sampling_kernel(const float* __restri
     // (seed, counter) -- the same numbers nerf_uniform_noise writes out
     float* cdf_s = s_rows + (size_t)wv * 2 * S;
     float* zl_s = cdf_s + S;
+    // (8-byte stores of sample pairs need even rows at 8-byte aligned bases)
+    const bool pair_stores = (Sf & 1) == 0 && ((((uintptr_t)out_a) | ((uintptr_t)out_b)) & 7) == 0;
     if (noise) {
-        const float* nz = noise + ray * Sf;
-        stage_sample_pdf<C>(pdf, zl, cdf_s, zl_s, S, lane, [&](int k) { return nz[k]; }, lin, Sf, out_a + ray * Sf,
-                            out_b ? out_b + ray * Sf : nullptr, inds ? inds + ray * Sf : nullptr);
+        const float* nrow = noise + ray * Sf;
+        stage_sample_pdf<C>(pdf, zl, cdf_s, zl_s, S, lane,
+                            [&](int k, float (&nz)[2]) { nz[0] = nrow[k]; nz[1] = k + 1 < Sf ? nrow[k + 1] : 0.f; }, lin, Sf,
+                            out_a + ray * Sf, out_b ? out_b + ray * Sf : nullptr, inds ? inds + ray * Sf : nullptr, pair_stores);
     } else {
         const uint64_t e0 = (uint64_t)ray * (uint64_t)Sf;
-        stage_sample_pdf<C>(pdf, zl, cdf_s, zl_s, S, lane, [&](int k) { return philox_uniform(seed, counter, e0 + (uint64_t)k); },
-                            lin, Sf, out_a + ray * Sf, out_b ? out_b + ray * Sf : nullptr, inds ? inds + ray * Sf : nullptr);
+        stage_sample_pdf<C>(pdf, zl, cdf_s, zl_s, S, lane,
+                            [&](int k, float (&nz)[2]) { philox_uniform2(seed, counter, e0 + (uint64_t)k, nz[0], nz[1]); }, lin, Sf,
+                            out_a + ray * Sf, out_b ? out_b + ray * Sf : nullptr, inds ? inds + ray * Sf : nullptr, pair_stores);
     }
 }
 

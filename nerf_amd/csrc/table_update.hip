@@ -30,7 +30,10 @@ constexpr int kPartFloats = NERF_PART_FLOATS;   // floats of one table partition
 #endif
 constexpr int kBinChunkPts = NERF_BIN_CHUNK;   // points per workgroup of the count / fill passes
 constexpr int kBinThreads = 1024;
-constexpr int kMaxBinsPerLevel = 8192;    // LDS histogram of the count / fill passes: 32 KB
+#ifndef NERF_MAX_BINS
+#define NERF_MAX_BINS 8192
+#endif
+constexpr int kMaxBinsPerLevel = NERF_MAX_BINS;    // LDS histogram of the count / fill passes: 32 KB
 static_assert(kPartFloats % 4 == 0 && kPartFloats <= 65536, "an item's partition-local offset is stored as uint16");
 static_assert(kMaxBinsPerLevel <= 65536, "the fill pass packs (bin, offset) into one 32-bit word");
 
