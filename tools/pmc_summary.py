@@ -33,7 +33,7 @@ ENTRY = [
     (r'sample_batch_kernel', 'nerf_sample_batch'),
     (r'composite_fwd_kernel', 'nerf_composite_fwd'),
     (r'composite_bwd_kernel', 'nerf_composite_bwd'),
-    (r'losses_kernel', 'nerf_losses'),
+    (r'losses_(sorted_)?kernel', 'nerf_losses'),
     (r'ray_sampling_kernel', 'nerf_coarse_to_fine'),
     (r'raygen_kernel', 'nerf_raygen'),
 ]

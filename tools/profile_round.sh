@@ -12,6 +12,9 @@ timeout -s KILL 120 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_I
 cd $R && python tools/pmc_summary.py --steps 4 --build $TAG --out $O/traffic.json $O/pmc_f $O/pmc_w > $O/pmc_traffic.txt
 cd $R/tools && python mfma_summary.py --build $TAG --out $O/mfma.json $O/pmc_m > $O/mfma.txt; cd $R
 find $O/prof -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
+# the per-ray kernels at 65 536 rays (where their bandwidth, not launch latency, is visible), under the kernel trace
+cd /tmp && timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_rays -o rays -- python $R/tools/per_ray_bench.py > $O/per_ray.json 2> $O/per_ray.err || exit 6
+cd $R; find $O/prof_rays -name "*kernel_stats.csv" -exec cp {} $O/per_ray_kernel_stats.csv \;
 find $O -name "*_kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete
 python -c "
 import json;d=json.loads(open('$O/bench.json').read().strip().splitlines()[-1]);print(d['ms_per_step'],d['value'],d['roofline'],d['cpu_baseline'],d['render'])"
