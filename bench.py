@@ -96,10 +96,14 @@ def build_gpu(device, rank, n_rays, pipeline=True, shard_levels=None):
     return model, renderer, loader, opt
 
 
+_NEXT_BATCH = {}        # loader id -> the batch Trainer.train_epoch's prefetch drew for the coming step (N > 1)
+
+
 def train_step(model, renderer, loader, opt, n_rays, it, world):
     from nerf_amd import helpers, parallel
     opt.zero_grad()
-    n, h, w, K, E, rgb_gt, color_bg, _ = loader.get_random_batch(n_rays)
+    batch = _NEXT_BATCH.pop(id(loader), None) or loader.get_random_batch(n_rays)
+    n, h, w, K, E, rgb_gt, color_bg, _ = batch
     lam_dist = 10 ** (it / 10000 * 3 - 5)            # trainer.py:160 with lambda 1e-5 -> 1e-2 over 10k iters
     if os.environ.get('NERF_FUSED_TAIL', '1') != '0':
         loss = renderer.render_loss(n, h, w, K, E, color_bg, rgb_gt, lam_dist, 1e-1)[0]   # what Trainer.train_step calls
@@ -112,6 +116,11 @@ def train_step(model, renderer, loader, opt, n_rays, it, world):
         parallel.backward_and_reduce(loss, model, [p for g in opt.param_groups for p in g['params']], skip=skip,
                                      flags=[opt.skip_flag])
         opt.grad_scale = 1.0 / world
+        if os.environ.get('NERF_PREFETCH_RAYS', '1') != '0':
+            # as Trainer.train_epoch: the next batch, its rays and the ray all-gather of its coarse pass before the optimizer step
+            nxt = loader.get_random_batch(n_rays)
+            renderer.prefetch_batch(*nxt[:5])
+            _NEXT_BATCH[id(loader)] = nxt
     else:
         loss.backward()
     opt.step()

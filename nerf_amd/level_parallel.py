@@ -185,10 +185,32 @@ class LevelSharding(object):
         self.inv = torch.tensor(inv, device=device, dtype=torch.int64)
         self._colmaps = {}
         self._group_perm = {}
+        self._prefetched = None  # (rays_o, rays_d, packed source, gathered rows, work) of prefetch_rays
         self.force = False      # run the exchange code even in a world of one rank (exercises the RCCL calls on one GPU)
         self.dirty = False      # True once an optimizer step made the non-owned levels of the local table stale
 
     # ---- point sources of all ranks -------------------------------------------------------
+    def prefetch_rays(self, rays_o, rays_d):
+        """Start the ray all-gather of the NEXT batch's coarse pass now (asynchronously): its depth table is shared, so the
+        collective needs nothing but the rays, which do not depend on the parameters.  Issued before the optimizer step,
+        it completes under the table update instead of standing, for its whole latency, at the top of the next step
+        (one of the exposed collectives of a sharded step).  The next plan() / gather_src() that is
+        handed these very tensors picks the result up; any other call gathers as usual."""
+        src = torch.cat([rays_o, rays_d], 1)
+        out, work = parallel.all_gather_rows(src, async_op=True)
+        self._prefetched = (rays_o, rays_d, src, out, work)
+
+    def _gather_rays(self, ro, rd):
+        pf, self._prefetched = self._prefetched, None
+        if pf is not None and pf[0] is ro and pf[1] is rd:
+            if pf[4] is not None:
+                pf[4].wait()
+            self.prefetch_hits = getattr(self, 'prefetch_hits', 0) + 1
+            return pf[3]
+        if pf is not None and pf[4] is not None:
+            pf[4].wait()            # a prefetch nobody asked for: let it finish before its buffers go away
+        return parallel.all_gather_rows(torch.cat([ro, rd], 1))
+
     def gather_src(self, kw):
         """kwargs of make_point_src for the points of ALL ranks (rank-major), from this rank's kwargs."""
         out = dict(outer_bound=kw['outer_bound'], inner_bound=kw.get('inner_bound', 0.0))
@@ -200,7 +222,7 @@ class LevelSharding(object):
         ro, rd = kw['rays_o'], kw['rays_d']
         S, zs = kw['n_samples'], kw.get('z_stride', 0)
         if zs == 0:     # one depth table shared by every ray of every rank
-            g = parallel.all_gather_rows(torch.cat([ro, rd], 1))
+            g = self._gather_rays(ro, rd)
             z = kw['z']
         else:
             g = parallel.all_gather_rows(torch.cat([ro, rd, kw['z'].view(ro.shape[0], zs)], 1))
@@ -289,7 +311,7 @@ class LevelSharding(object):
         S, zs = kw['n_samples'], kw.get('z_stride', 0)
         perm = perm.to(ro.device)
         if zs == 0:
-            g = parallel.all_gather_rows(torch.cat([ro, rd], 1)).index_select(0, perm)
+            g = self._gather_rays(ro, rd).index_select(0, perm)
             z = kw['z']
         else:
             g = parallel.all_gather_rows(torch.cat([ro, rd, kw['z'].view(ro.shape[0], zs)], 1)).index_select(0, perm)

@@ -206,20 +206,23 @@ def _stage_cpu(t):
     return dist.get_backend() == 'gloo' and t.is_cuda
 
 
-def all_gather_rows(local):
-    """[R, ...] on every rank -> [world*R, ...], rank-major (equal R on all ranks)."""
+def all_gather_rows(local, async_op=False):
+    """[R, ...] on every rank -> [world*R, ...], rank-major (equal R on all ranks).
+    async_op: returns (out, work); `out` is valid on the current stream after work.wait() (work is None when the backend
+    ran the collective synchronously)."""
     world = world_size()
     if not dist.is_initialized():
-        return local
+        return (local, None) if async_op else local
     local = local.contiguous()
     if _stage_cpu(local):
         src = local.cpu()
         out = torch.empty((world * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype)
         dist.all_gather_into_tensor(out, src)
-        return out.to(local.device)
+        out = out.to(local.device)
+        return (out, None) if async_op else out
     out = local.new_empty((world * local.shape[0],) + tuple(local.shape[1:]))
-    dist.all_gather_into_tensor(out, local)
-    return out
+    work = dist.all_gather_into_tensor(out, local, async_op=async_op)
+    return (out, work) if async_op else out
 
 
 def all_to_all_blocks(recv_blocks, send_blocks, async_op=False):

@@ -150,6 +150,22 @@ class NerfRenderer(nn.Module):
 
     ## Rendering Pipeline
 
+    def prefetch_batch(self, n, h, w, K, E):
+        """Prepare the NEXT batch while the current step's optimizer pass is still to come: generate its rays and, under a
+        level-sharded table, start the ray all-gather of its coarse pass (LevelSharding.prefetch_rays) -- neither depends on
+        the parameters.  render() / render_loss() called with these very tensors picks both up; no counterpart in the
+        reference, whose step is single-GPU (trainer.py:143-150)."""
+        rays_o, rays_d = self.get_rays(h, w, K, E)
+        self._prefetched_rays = (h, w, K, E, rays_o, rays_d)
+        if isinstance(self.model, NeRFNetwork) and self.model._sharded():
+            self.model.level_sharding.prefetch_rays(rays_o, rays_d)
+
+    def _rays_for(self, h, w, K, E):
+        pf, self._prefetched_rays = getattr(self, '_prefetched_rays', None), None
+        if pf is not None and pf[0] is h and pf[1] is w and pf[2] is K and pf[3] is E:
+            return pf[4], pf[5]
+        return self.get_rays(h, w, K, E)
+
     def get_rays(self, h, w, K, E):
         """renderer.py:38-48."""
         hh, ww, KK, EE = i64(h).reshape(-1), i64(w).reshape(-1), f32(K).reshape(-1, 3, 3), f32(E).reshape(-1, 4, 4)
@@ -299,7 +315,7 @@ class NerfRenderer(nn.Module):
     def render(self, n, h, w, K, E, bg_color, noise=None, generator=None, aux=True, train_loss=None):
         """renderer.py:170-194.  ``aux=False`` (inference only, no grad): the per-sample aux outputs ``xyzs`` and
         ``x_hashtable`` are not produced (172 B per sample that render_image never reads)."""
-        rays_o, rays_d = self.get_rays(h, w, K, E)
+        rays_o, rays_d = self._rays_for(h, w, K, E)
         z_vals_log, z_vals = self.efficient_sampling(rays_o, rays_d, self.steps_importance, self.alpha_importance,
                                                      noise=noise, generator=generator)
         N, Sf = z_vals.shape

@@ -132,6 +132,12 @@ class Trainer(object):
                     self.optimizer.grad_scale = 1.0 / world
             else:
                 loss.backward()
+            if world > 1 and hasattr(self.renderer, 'prefetch_batch'):
+                # the next iteration's batch, its rays and (level-sharded table) the ray all-gather of its coarse pass are
+                # issued BEFORE the optimizer step: they depend on no parameter, and the collective then completes under
+                # the table update instead of opening the next step.  Same batches in the same order.
+                self._next_batch = self.dataloader.get_random_batch(self.n_rays)
+                self.renderer.prefetch_batch(*self._next_batch[:5])
             self.optimizer.step()
             if self.scheduler is not None:
                 self.scheduler.step()
@@ -153,7 +159,10 @@ class Trainer(object):
 
     def train_step(self):
         self.model.train()
-        n, h, w, K, E, rgb_gt, color_bg, _ = self.dataloader.get_random_batch(self.n_rays)
+        batch, self._next_batch = getattr(self, '_next_batch', None), None
+        if batch is None:
+            batch = self.dataloader.get_random_batch(self.n_rays)
+        n, h, w, K, E, rgb_gt, color_bg, _ = batch
         dist_scalar, depth_scalar = self.loss_lambdas()
         if hasattr(self.renderer, 'render_loss'):
             # trainer.py:149-169 with compositing and the three losses in one kernel (and one for their backward)

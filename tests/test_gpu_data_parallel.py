@@ -17,7 +17,7 @@ KW = dict(encoding_precision='float32', encoding_n_levels=8, encoding_n_features
           encoding_log2_hashmap_size=15, geo_feat_dim=15, sigma_hidden_dim=64, sigma_num_layers=2,
           encoding_dir_precision='float32', encoding_dir_encoding='SphericalHarmonics', encoding_dir_degree=4,
           latent_embedding_dim=48, color_hidden_dim=64, color_num_layers=3)
-N, STEPS = 126, 3       # divisible by 2 and 3: the level-sharded exchange needs the same ray count on every rank
+N, STEPS = 132, 3       # divisible by 2, 3 and 4: the level-sharded exchange needs the same ray count on every rank
 
 
 def _batches():
@@ -46,9 +46,10 @@ def _train(rank, world, log2_T=15):
     opt = FusedAdam([{'params': list(net.encoder.parameters()) + [net.latent_emb], 'lr': 2e-2},
                      {'params': list(net.sigma_net.parameters()) + list(net.color_net.parameters()), 'lr': 1e-3,
                       'weight_decay': 1e-6}], betas=(0.9, 0.99), eps=1e-15).attach(net)
-    for b in _batches():
-        a, e = parallel.shard_range(N, rank, world)
-        n, h, w, K, E, bg, noise, gt = [t[a:e].cuda() if t.dim() > 0 and t.shape[0] == N else t.cuda() for t in b]
+    prefetch = world > 1 and os.environ.get('NERF_TEST_PREFETCH') == '1'
+    a, e = parallel.shard_range(N, rank, world)
+    mine = [[t[a:e].cuda() if t.dim() > 0 and t.shape[0] == N else t.cuda() for t in b] for b in _batches()]
+    for i, (n, h, w, K, E, bg, noise, gt) in enumerate(mine):
         opt.zero_grad()
         img, wts, zs, _ = R.render(n, h, w, K, E, bg, noise=noise)
         loss, _ = helpers.fused_train_loss(img, gt, wts, zs, 1e-3, 1e-1)
@@ -66,11 +67,17 @@ def _train(rank, world, log2_T=15):
                 assert skip, 'the table gradient must not need an all-reduce of its own'
                 parallel.all_reduce_grads(params, skip=skip)
                 opt.grad_scale = 1.0 / world
+        if prefetch and i + 1 < STEPS:
+            # Trainer.train_epoch / bench.py: the next batch's rays and the ray all-gather of its coarse pass are issued
+            # before the optimizer step and picked up by the next render()
+            R.prefetch_batch(*mine[i + 1][:5])
         opt.step()
     if world > 1:
         assert (net.level_sharding is not None) == (os.environ.get('NERF_TABLE_PARALLEL') != '0')
         if net.level_sharding is not None and int(os.environ.get('NERF_SHARD_GROUPS', '1')) != 1:
             assert net.level_sharding.early_reduces == STEPS        # the hook fired once per backward pass
+    if prefetch and net.level_sharding is not None:
+        assert net.level_sharding.prefetch_hits == STEPS - 1, getattr(net.level_sharding, 'prefetch_hits', 0)
     if log2_T >= 19 and (world == 1 or net.level_sharding is not None):
         # levels 5-7 are hashed and large enough for the binned table update (every rank together owns all three)
         assert world > 1 or net.table_pipeline.binned_levels == [5, 6, 7], net.table_pipeline.binned_levels
@@ -80,9 +87,10 @@ def _train(rank, world, log2_T=15):
     return [p.detach().cpu() for p in (net.encoder.params, net.sigma_net.params, net.color_net.params, net.latent_emb)]
 
 
-def _worker(rank, world, port, q, mode, log2_T, groups):
+def _worker(rank, world, port, q, mode, log2_T, groups, prefetch=False):
     os.environ['NERF_TABLE_PARALLEL'] = '1' if mode == 'sharded' else '0'
     os.environ['NERF_SHARD_GROUPS'] = str(groups)
+    os.environ['NERF_TEST_PREFETCH'] = '1' if prefetch else '0'
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -93,22 +101,25 @@ def _worker(rank, world, port, q, mode, log2_T, groups):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('mode,world,log2_T,groups', [('dp', 2, 15, 1), ('sharded', 2, 15, 1), ('sharded', 3, 15, 1),
-                                                      ('sharded', 2, 19, 1), ('dp', 2, 19, 1), ('sharded', 2, 15, 3),
-                                                      ('sharded', 3, 19, 2), ('sharded', 2, 19, 4)])
-def test_multi_rank_training_matches_single_process(mode, world, log2_T, groups):
+@pytest.mark.parametrize('mode,world,log2_T,groups,prefetch', [
+    ('dp', 2, 15, 1, False), ('sharded', 2, 15, 1, False), ('sharded', 3, 15, 1, False), ('sharded', 2, 19, 1, False),
+    ('dp', 2, 19, 1, False), ('sharded', 2, 15, 3, False), ('sharded', 3, 19, 2, False), ('sharded', 2, 19, 4, True),
+    ('sharded', 4, 19, 2, True)])
+def test_multi_rank_training_matches_single_process(mode, world, log2_T, groups, prefetch):
     """world 3 puts a rank in the middle (remote points on both sides of its own block) and splits 8 levels 3/3/2.
     log2_T 19 makes levels 5-7 hashed and large: the single process and the level owners then take the binned table
     update (csrc/table_update.hip), the replicated 'dp' ranks the scatter -> all-reduce -> Adam pipeline.
     groups > 1: both feature exchanges run per ray group (level_parallel.LevelSharding.plan; 63 or 42 rays per rank in
-    groups of 21 / 15-16 / 10-11 rays), the owners see the points of all ranks in group-major order."""
+    groups of 22 / 16-17 / 11 rays), the owners see the points of all ranks in group-major order.  world 4 with two ray
+    groups splits the 8 levels 2/2/2/2 over four ranks on the one GPU.  prefetch: the ray all-gather of the next batch's
+    coarse pass is issued before the optimizer step (NerfRenderer.prefetch_batch) and must be the one the next step uses."""
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode, log2_T, groups)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode, log2_T, groups, prefetch)) for r in range(world)]
     [p.start() for p in procs]
     got = q.get(timeout=150)
     [p.join(60) for p in procs]

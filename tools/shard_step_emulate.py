@@ -84,10 +84,10 @@ def main():
         torch.cuda.current_stream().wait_event(done)
         return None
 
-    def fake_gather(t):
+    def fake_gather(t, async_op=False):
         out = t.repeat(*([W] + [1] * (t.dim() - 1)))
-        on_wire(t.numel() * t.element_size(), False)      # every peer sends me its block over its own link
-        return out
+        work = on_wire(t.numel() * t.element_size(), async_op)      # every peer sends me its block over its own link
+        return (out, work) if async_op else out
     parallel.all_gather_rows = fake_gather
 
     def fake_a2a(recv_blocks, send_blocks, async_op=False):
