@@ -1,7 +1,8 @@
 """The level-sharded training step over REAL RCCL (backend "nccl") in a world of one rank: the only way to run the
 RCCL calls of nerf_amd.parallel on a one-GPU box (RCCL refuses two ranks on one device).  A world of one is the
 degenerate case of the same code: all_gather_into_tensor, the list all-to-all whose own block is an empty tensor
-(async + wait), the packed all-reduce of the small gradients, the per-level broadcasts of sync_table, barrier.
+(async + wait), the asynchronous ray all-gather a step issues for the NEXT batch (NerfRenderer.prefetch_batch), the packed
+all-reduce of the small gradients, the per-level broadcasts of sync_table, barrier.
 Runs in a child process so that the process group does not leak into the other tests."""
 import os
 import socket
@@ -39,7 +40,11 @@ def train(shard, cfg="small"):
         loss.backward()
         skip = [opt._table_param] if opt.table_reduced_by_pipeline() else []
         parallel.all_reduce_grads([p for g in opt.param_groups for p in g["params"]], skip=skip)
+        if shard:       # the next step's ray all-gather, asynchronous over RCCL, issued before the optimizer step
+            R.prefetch_batch(n, h, w, K, E)
         opt.step()
+    if shard:
+        assert net.level_sharding.prefetch_hits == 2, getattr(net.level_sharding, "prefetch_hits", 0)
     net.sync_table()
     torch.cuda.synchronize()
     return float(loss), [p.detach().clone() for p in (net.encoder.params, net.sigma_net.params, net.color_net.params, net.latent_emb)]
@@ -78,6 +83,10 @@ assert float(flag) == 3.0 and float(w_.grad.sum()) == 8.0
 # the helpers directly, incl. the empty own block of the list all-to-all
 x = torch.arange(12., device="cuda").view(4, 3)
 assert torch.equal(parallel.all_gather_rows(x), x)
+g_out, g_work = parallel.all_gather_rows(x, async_op=True)
+if g_work is not None:
+    g_work.wait()
+assert torch.equal(g_out, x)
 send, recv = torch.ones(5, device="cuda"), torch.zeros(5, device="cuda")
 work = parallel.all_to_all_blocks([recv], [send], async_op=True)
 if work is not None:
