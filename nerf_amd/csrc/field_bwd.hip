@@ -16,7 +16,70 @@ int nerf_check_src(const char* fn, const NerfPointSrc* src, bool with_color);
 namespace {
 
 constexpr int kBlockPts = 128;
+#ifndef NERF_DW_BF16
+#define NERF_DW_BF16 1
+#endif
+#ifndef NERF_DW_G
+#define NERF_DW_G 1          // 16-byte operand pairs read ahead of the MFMAs of a dW tile
+#endif
+#ifndef NERF_BWD_XF_PREFETCH
+#define NERF_BWD_XF_PREFETCH (NERF_DW_BF16 ? 0 : 1)     // 1: the feature half row a whole tile ahead (20 registers the packed staging cannot spare); 2: from the end of the previous tile; 0: at the tile's top
+#endif
+#if NERF_DW_BF16
+// The weight-gradient products dW = dZ * H^T run on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, 16x the f32-input rate)
+// with both operands split in two: every staged value v is kept as the pair (hi, lo) of bf16 halves, hi = v truncated to
+// bf16, lo = (v - hi) rounded to bf16 (v - hi is exact in fp32), |v - hi - lo| <= 2^-16 |v|.  A staged word holds (hi, lo) of
+// one point, so the 8 k-slots of a lane are 4 points x (hi, lo); one MFMA on the words as staged sums hi*hi + lo*lo over
+// 8 points, a second one with A's halves swapped sums lo*hi + hi*lo: all four terms, fp32 accumulation, 2 x 32 cycles per
+// 8 points against 4 x 64 for the f32-input MFMA.  The MLP chains themselves stay exact fp32; a weight
+// gradient is a sum over 500 k points and tolerates 2^-16 per term (gradient bar 1e-3).
+constexpr int kSP = kBlockPts + 4;  // staging pitch in words: rows stay 16-byte aligned, 16 rows x 4 words cover the 64 banks
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float split_pack(float v) {
+    const float hi = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) & 0xffff0000u);     // exact in bf16
+    const f32x2v pair = {hi, v - hi};
+    return __builtin_bit_cast(float, __builtin_convertvector(pair, bf16x2v));      // v_cvt_pk_bf16_f32: low half hi, high half rne(lo)
+}
+#define STG(v) split_pack(v)
+
+// acc += SA[a_tile rows][:] * SB[b_tile rows][:]^T over the 128 staged points
+__device__ __forceinline__ f32x16 dw_tile(f32x16 acc, const float* SA, const float* SB, int a_tile, int b_tile, int n_out,
+                                          int n_in, int l31, int h) {
+    // rows past n_out / n_in are clamped to row 0: they land in accumulator entries flush_tile never writes
+    const int ar = a_tile * 32 + l31, br = b_tile * 32 + l31;
+    const u32x4* pa = (const u32x4*)(SA + (ar < n_out ? ar : 0) * kSP + 4 * h);     // lane half h: points 8 s + 4 h ...
+    const u32x4* pb = (const u32x4*)(SB + (br < n_in ? br : 0) * kSP + 4 * h);
+    constexpr int NS = kBlockPts / 8, G = NERF_DW_G, NG = NS / G;
+    u32x4 abuf[2][G], bbuf[2][G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) { abuf[0][i] = pa[2 * i]; bbuf[0][i] = pb[2 * i]; }
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+        if (gi + 1 < NG) {
+#pragma unroll
+            for (int i = 0; i < G; ++i) { abuf[(gi + 1) & 1][i] = pa[2 * ((gi + 1) * G + i)]; bbuf[(gi + 1) & 1][i] = pb[2 * ((gi + 1) * G + i)]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const u32x4 a = abuf[gi & 1][i], b = bbuf[gi & 1][i];
+            u32x4 asw;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) asw[e] = __builtin_amdgcn_alignbit(a[e], a[e], 16);      // swap the two halves
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, asw), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return acc;
+}
+#else
 constexpr int kSP = kBlockPts + 1;  // staging pitch (odd -> conflict-free row walks)
+#define STG(v) (v)
 
 // acc += SA[a_tile rows][:] * SB[b_tile rows][:]^T over the 128 staged points
 __device__ __forceinline__ f32x16 dw_tile(f32x16 acc, const float* SA, const float* SB, int a_tile, int b_tile, int n_out,
@@ -42,13 +105,17 @@ __device__ __forceinline__ f32x16 dw_tile(f32x16 acc, const float* SA, const flo
     }
     return acc;
 }
+#endif
 
 // stage a 64-row P-layout activation pair as [unit][point]
 __device__ __forceinline__ void stage64(float* S, int col, int h, const f32x16& v0, const f32x16& v1) {
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
-        S[(krow(t) + 4 * h) * kSP + col] = v0[t];
-        S[(32 + krow(t) + 4 * h) * kSP + col] = v1[t];
+        S[(krow(t) + 4 * h) * kSP + col] = STG(v0[t]);
+        S[(32 + krow(t) + 4 * h) * kSP + col] = STG(v1[t]);
+#if NERF_DW_BF16
+        if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);       // keep the packing temporaries of a few elements alive, not of all 32
+#endif
     }
 }
 
@@ -137,7 +204,10 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
         PointIn q;
         float dsig, dr0, dr1, dr2;
         const float *xrow, *lrow;
-        float xf[XF], lat[24];
+        float xf[XF];
+#if !NERF_DW_BF16
+        float lat[24];
+#endif
     };
     auto request = [&](int64_t bt, TileIn& t) {
         const int64_t p_raw = bt * kBlockPts + col;
@@ -150,11 +220,20 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
         // (an image index outside the latent table: zero latent row, no latent gradient -- as in the forward)
         t.n_ok = (uint64_t)t.q.n < (uint64_t)s.n_img;
         t.lrow = latent + (t.n_ok ? t.q.n : 0) * s.lat + h * s.lat_half;
+#if NERF_BWD_XF_PREFETCH == 1
         load_features<XF>(t.xf, t.xrow, LHF, LF, h, vec);
+#endif
+#if !NERF_DW_BF16
         load_latent_half(t.lat, t.lrow, s.lat_half);
+#endif
     };
     TileIn nxt;
-    if ((int64_t)blockIdx.x < n_btiles) request(blockIdx.x, nxt);
+    if ((int64_t)blockIdx.x < n_btiles) {
+        request(blockIdx.x, nxt);
+#if NERF_BWD_XF_PREFETCH == 2
+        load_features<XF>(nxt.xf, nxt.xrow, LHF, LF, h, vec);
+#endif
+    }
     for (int64_t bt = blockIdx.x; bt < n_btiles; bt += gridDim.x) {
         const bool valid = nxt.valid, n_ok = nxt.n_ok;
         const int64_t p = nxt.p;
@@ -164,10 +243,22 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
         const float* xrow = nxt.xrow;
         const float* lrow = nxt.lrow;
         float xf[XF], lat[24];
+#if NERF_BWD_XF_PREFETCH
 #pragma unroll
         for (int t = 0; t < XF; ++t) xf[t] = nxt.xf[t];
+#else
+        load_features<XF>(xf, xrow, LHF, LF, h, vec);
+#endif
+#if NERF_DW_BF16
+        // (the latent half row is requested here, not a tile ahead: 24 registers less across the whole tile, which the
+        // packed staging needs; it is consumed only after the two sigma layers)
+        load_latent_half(lat, lrow, s.lat_half);
+#pragma unroll
+        for (int t = 0; t < 24; ++t) lat[t] = n_ok ? lat[t] : 0.f;
+#else
 #pragma unroll
         for (int t = 0; t < 24; ++t) lat[t] = n_ok ? nxt.lat[t] : 0.f;
+#endif
         // ------------------------- forward recompute -------------------------
         f32x16 a0, a1;
         {
@@ -208,9 +299,9 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
         }
         __syncthreads();  // previous iteration's readers of SA/SB are done
         if (h == 0) {
-            SA[0 * kSP + col] = d3[0];
-            SA[1 * kSP + col] = d3[1];
-            SA[2 * kSP + col] = d3[2];
+            SA[0 * kSP + col] = STG(d3[0]);
+            SA[1 * kSP + col] = STG(d3[1]);
+            SA[2 * kSP + col] = STG(d3[2]);
         }
         stage64(SB, col, h, e0, e1);
         __syncthreads();
@@ -243,7 +334,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const int row = krow(t) + 4 * h;
-            if (row >= 1) SB[(row - 1) * kSP + col] = o2[t];
+            if (row >= 1) SB[(row - 1) * kSP + col] = STG(o2[t]);
         }
         {
             float sh2[16];
@@ -253,13 +344,13 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
                 if (t < s.sh_half) {
                     float b = h ? sh2[8 + t] : sh2[t];
                     if (s.sh_half == 2) b = h ? sh2[2 + t] : sh2[t];
-                    SB[(15 + h * s.sh_half + t) * kSP + col] = b;
+                    SB[(15 + h * s.sh_half + t) * kSP + col] = STG(b);
                 }
             }
         }
 #pragma unroll
         for (int t = 0; t < 24; ++t)
-            if (t < s.lat_half) SB[(15 + s.sh_dim + h * s.lat_half + t) * kSP + col] = lat2[t];
+            if (t < s.lat_half) SB[(15 + s.sh_dim + h * s.lat_half + t) * kSP + col] = STG(lat2[t]);
         __syncthreads();
         acc_c1 = dw_tile(acc_c1, SA, SB, wave / in_c_tiles, wave % in_c_tiles, kHid, s.in_c, l31, h);
         if (wave < 2 && 4 + wave < 2 * in_c_tiles)
@@ -323,7 +414,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
         if (h == 0) d2[0] = o2[0] > 0.f ? dsig : 0.f;
         __syncthreads();
 #pragma unroll
-        for (int t = 0; t < 8; ++t) SA[(krow(t) + 4 * h) * kSP + col] = d2[t];
+        for (int t = 0; t < 8; ++t) SA[(krow(t) + 4 * h) * kSP + col] = STG(d2[t]);
         stage64(SB, col, h, a0, a1);
         __syncthreads();
         float xf2[XF];
@@ -337,9 +428,14 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
         stage64(SA, col, h, g0, g1);
 #pragma unroll
         for (int t = 0; t < XF; ++t)
-            if (t < LHF) SB[(h * LHF + t) * kSP + col] = xf2[t];
+            if (t < LHF) SB[(h * LHF + t) * kSP + col] = STG(xf2[t]);
         __syncthreads();
         acc_s1 = dw_tile(acc_s1, SA, SB, wave >> 1, wave & 1, kHid, s.in_sp, l31, h);
+#if NERF_BWD_XF_PREFETCH == 2
+        // the next tile's feature half row is requested HERE, late in the tile (its registers are free only now): it lands
+        // under the last chain and the stores below instead of at the top of the next tile
+        if (bt + gridDim.x < n_btiles) load_features<XF>(nxt.xf, nxt.xrow, LHF, LF, h, vec);
+#endif
         // d(features): row map chosen so that each lane receives the gradients of its OWN levels:
         // register t of tile T <-> internal feature h*LHF + 16*T + t
         f32x16 x0 = zero16(), x1 = zero16();

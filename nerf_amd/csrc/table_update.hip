@@ -348,6 +348,9 @@ __global__ __launch_bounds__(kBinThreads) void bin_fill_sorted_kernel(GridDev g,
 // once, measured SLOWER (2.00 vs 1.92 ms on one box): the stream wants consecutive blocks on consecutive addresses.
 // (Measured on one box, update pass alone: quarters 1.86 ms; halves 1.96; eighths 1.89; quarters with every item's
 // values requested together with its index, before the quarter test, 1.90.)
+#ifndef NERF_UPD_VARIANT
+#define NERF_UPD_VARIANT 0      // 1: timing variant of the update pass (tools/ab builds only)
+#endif
 constexpr int kSubFloats = 4096;
 constexpr int kSubs = kPartFloats / kSubFloats;
 constexpr int kSplitThreads = 256;
@@ -383,14 +386,19 @@ __global__ __launch_bounds__(kSplitThreads) void table_update_kernel(GridDev g, 
     // this thread's p, m, v: requested first, they arrive while the bin is summed
     const int64_t base4 = ((int64_t)g.offset[l] * F + f0) >> 2;            // (arithmetic shift: f0 may be negative)
     f4 pq[kQuads], mq[kQuads], vq[kQuads];
+    auto request_pmv = [&] {
 #pragma unroll
-    for (int u = 0; u < kQuads; ++u) {
-        const int i = tid + u * T;
-        const int64_t a = base4 + ((i >= q_lo && i < q_hi) ? i : q_lo);
-        pq[u] = __builtin_nontemporal_load((const f4*)p + a);
-        mq[u] = __builtin_nontemporal_load((const f4*)m + a);
-        vq[u] = __builtin_nontemporal_load((const f4*)v + a);
-    }
+        for (int u = 0; u < kQuads; ++u) {
+            const int i = tid + u * T;
+            const int64_t a = base4 + ((i >= q_lo && i < q_hi) ? i : q_lo);
+            pq[u] = __builtin_nontemporal_load((const f4*)p + a);
+            mq[u] = __builtin_nontemporal_load((const f4*)m + a);
+            vq[u] = __builtin_nontemporal_load((const f4*)v + a);
+        }
+    };
+#if NERF_UPD_VARIANT == 0
+    request_pmv();
+#endif
 #pragma unroll
     for (int u = 0; u < kQuads; ++u) acc4[tid + u * T] = zero;
     // lgkmcnt(0) only: the loads above stay in flight across the barrier ("memory": a compiler-level fence for the LDS
@@ -450,6 +458,9 @@ __global__ __launch_bounds__(kSplitThreads) void table_update_kernel(GridDev g, 
     } else {
         for (int64_t i = i0 + tid; i < i1; i += T) add_item(i, item_idx[i]);
     }
+#if NERF_UPD_VARIANT == 1
+    request_pmv();      // (timing variant: sum the bin first, then stream)
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
     for (int u = 0; u < kQuads; ++u) {
