@@ -171,7 +171,10 @@ int nerf_field_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const float* 
 /* Backward of nerf_field_fwd (what autograd + tcnn do under trainer.py:134).  Gradients are
  * ACCUMULATED into dtable / dsigma_params / dcolor_params / dlatent (caller zeroes them).
  * dfeat [M, L*F] receives d(loss)/d(hash-grid features) (it is also the staging buffer between the
- * MLP-backward launch and the table-scatter launch); dtable may be NULL to skip the scatter. */
+ * MLP-backward launch and the table-scatter launch); dtable may be NULL to skip the scatter.
+ * Precision: the forward recompute, the back-propagated gradients, dfeat and dlatent are exact fp32 (f32-input MFMA);
+ * the weight-gradient sums dW = sum over points of dZ * H^T run on the bf16 matrix cores with both operands split into
+ * bf16 (hi, lo) halves, all four cross terms, fp32 accumulation: 2^-16 relative per term. */
 int nerf_field_bwd(const NerfGridCfg* grid, const NerfNetCfg* net, const float* table, const float* sigma_params,
                    const float* color_params, const float* latent_emb, int64_t n_images, const NerfPointSrc* src,
                    const float* x_hashtable, const float* dsigma /*[M]*/, const float* drgb /*[M,3]*/,
