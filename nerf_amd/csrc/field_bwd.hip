@@ -164,8 +164,12 @@ __device__ __forceinline__ f32x16 relu_mask(const f32x16& d, const f32x16& act) 
     return r;
 }
 
+// REF: the reference's colour-net input (SH degree 4 + latent 48): its layer-1 input map is a compile-time function and
+// the colour net's shape numbers are constants, which takes ~200 uniform values and shape tests out of the scalar registers
+// (262 -> 67 SGPRs spilled into VGPR lanes; 0.520 -> 0.504 ms).  Making the grid's shape constant as well (exactly 2 * XF
+// features: no SGPR spills at all) measured SLOWER, 0.558 ms: the allocator then spills 54 vector registers instead of 27.
 template <int F, int XF, bool REF>
-__global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, const float* __restrict__ sigma_w,
+__global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s_in, const float* __restrict__ sigma_w,
                                                            const float* __restrict__ color_w,
                                                            const float* __restrict__ latent, NerfPointSrc src,
                                                            const float* __restrict__ xh, const float* __restrict__ dsigma,
@@ -173,6 +177,8 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s, 
                                                            float* __restrict__ dsw, float* __restrict__ dcw,
                                                            float* __restrict__ dlatent, int sb_rows) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    NetLds s = s_in;
+    if (REF) { s.sh_dim = 16; s.sh_half = 8; s.lat = 48; s.lat_half = 24; s.in_c = 79; }
     lds_load_net(lds, s, sigma_w, color_w, true);
     float* SA = lds + s.total;
     float* SB = SA + kHid * kSP;
@@ -524,7 +530,7 @@ extern "C" int nerf_field_bwd(const NerfGridCfg* grid, const NerfNetCfg* net, co
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH3(FF, XX, RR)                                                                                            \
     do {                                                                                                               \
-        auto kern = field_bwd_kernel<FF, XX, RR>;                                                                        \
+        auto kern = field_bwd_kernel<FF, XX, (RR)>;                                                                      \
         static NerfLdsAttrCache lds_cache = {};   /* per instantiation */    \
         if (int e = nerf_ensure_dynamic_lds((const void*)kern, lds_bytes, &lds_cache, "field_bwd")) return e;    \
         kern<<<nb, 256, lds_bytes, st>>>(g, s, sigma_params, color_params, latent_emb, *src, x_hashtable, dsigma, drgb, \
