@@ -15,6 +15,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef NERF_CHAIN_PROBE
+#define NERF_CHAIN_PROBE 0
+#endif
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 constexpr int kHid = 64;
@@ -318,7 +321,15 @@ __device__ __forceinline__ void mfma_chain(f32x16 (&acc)[NT], AFn a_at, BFn b_at
         for (int s = 0; s < G; ++s)
 #pragma unroll
             for (int n = 0; n < NT; ++n)
-                if (g * G + s < STEPS) acc[n] = MFMA32(buf[g & 1][s * NT + n], b_at(g * G + s), acc[n]);
+                if (g * G + s < STEPS) {
+#if NERF_CHAIN_PROBE
+                    // timing probe only (wrong values): what the chains would cost at 3/8 of their matrix-core cycles, every LDS read kept
+                    if ((g * G + s) % 8 < 3) acc[n] = MFMA32(buf[g & 1][s * NT + n], b_at(g * G + s), acc[n]);
+                    else asm volatile("" :: "v"(buf[g & 1][s * NT + n]));
+#else
+                    acc[n] = MFMA32(buf[g & 1][s * NT + n], b_at(g * G + s), acc[n]);
+#endif
+                }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
