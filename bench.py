@@ -326,6 +326,8 @@ def main():
                     "SURVEY's light variant is --levels 16 --table-log2 19)")
     ap.add_argument('--coarse', default='64', help="coarse sampling: '64' (metric config, z_bounds [1.6,4.8]) or "
                     "'480' (config_base: steps [256,128,64,32], z_bounds [.1,1,10,100,1000]; SURVEY C1/C4 parity sizes)")
+    ap.add_argument('--table-precision', default='float32', choices=['float32', 'float16'],
+                    help="REHEARSAL ONLY: 'float16' gathers from a half-precision image of the table (the metric config is float32)")
     ap.add_argument('--hang-trace', type=int, default=0, help='dump all Python stacks to stderr every N seconds')
     args = ap.parse_args()
     if args.hang_trace > 0:
@@ -344,6 +346,7 @@ def main():
 
     NET['encoding_log2_hashmap_size'] = args.table_log2
     NET['encoding_n_levels'] = args.levels
+    NET['encoding_precision'] = args.table_precision
     if args.coarse == '480':
         STEPS[:] = [256, 128, 64, 32]
         Z_BOUNDS[:] = [0.1, 1, 10, 100, 1000]
@@ -451,6 +454,7 @@ def main():
     tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
     # (the PMC passes were taken at N = 1 on the default table and batch: per-launch traffic of any other run is unmeasured)
     default_workload = (args.rays == 4096 and args.table_log2 == 24 and args.levels == 20 and args.coarse == '64'
+                        and args.table_precision == 'float32'
                         and os.environ.get('NERF_TABLE_BINNED', '1') != '0')
     pmc = json.load(open(tpath)) if os.path.exists(tpath) and world == 1 and default_workload else {}
 
@@ -554,7 +558,8 @@ def main():
             'config': {'workload': ('train step (render + backward + dense Adam), %d rays/GPU/step, %d coarse + 128 fine '
                                     'samples/ray, config_base network (L%d F2 T%d, SH4, latent 48, 64-wide MLPs), '
                                     'procedural scene 100 poses 800x800' % (args.rays, sum(STEPS), args.levels, args.table_log2))
-                                   + ('' if args.coarse == '64' else ' [NOT the metric config: %s coarse samples]' % args.coarse),
+                                   + ('' if args.coarse == '64' else ' [NOT the metric config: %s coarse samples]' % args.coarse)
+                                   + ('' if args.table_precision == 'float32' else ' [NOT the metric config: half-precision table image]'),
                        'rays_per_gpu': args.rays, 'global_rays': args.rays * world,
                        'table_mode': ('single_gpu' if world == 1 else
                                       ('level_sharded' if getattr(model_sharded, 'world', 1) > 1 else 'replicated_fallback')),

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NERF_ABI_VERSION 3
+#define NERF_ABI_VERSION 4
 #define NERF_MAX_LEVELS 32
 #define NERF_MAX_SEGMENTS 16
 #define NERF_MAX_SAMPLES 512 /* per-ray kernels: one wavefront per ray, at most 8 samples per lane */
@@ -226,6 +226,30 @@ typedef struct NerfColMap {
  * direction 1: flat[offset[c] + p*stride[c]] = matrix[p*n_cols + c]   (split d(features) before the all-to-all) */
 int nerf_feature_shuffle(const float* src, float* dst, int64_t n_rows, int n_cols, const NerfColMap* map, int direction,
                          void* stream);
+
+/* ---- half-precision gather copy of the table: `precision: float16` (nets.py:31-36, passed to tcnn.Encoding as dtype at
+ * nets.py:49) ----
+ * tinycudann keeps fp32 master parameters (what torch.optim.Adam updates, train.py:84-88) and evaluates the encoding
+ * from their fp16 image.  Here the image is a second buffer of total_entries * n_features _Float16 that the caller
+ * refreshes with nerf_table_to_half after every parameter update (4 B read + 2 B written per parameter), and the
+ * `_f16` forms of the entry points that READ the table gather from it: entries are widened on load, the trilinear
+ * blend and everything downstream stay fp32 (the reference blends and emits fp16: this path is at least as precise;
+ * tinycudann is absent, so its fp16 arithmetic is unpinned -- the parity bar of these entry points is the oracle with
+ * its table rounded to fp16, tests/test_gpu_half_table.py).  Arguments, errors and outputs are those of the
+ * fp32 forms; gradients (nerf_field_bwd, the scatter / bin passes) never read the table and need no `_f16` form. */
+int nerf_table_to_half(const float* table, void* table_f16, int64_t count /* floats */, void* stream);
+int nerf_hashgrid_fwd_f16(const NerfGridCfg* grid, const void* table_f16, const float* x01 /*[M,3]*/, int64_t n_points,
+                          float* out /*[M,L*F]*/, void* stream);
+int nerf_density_fwd_f16(const NerfGridCfg* grid, const NerfNetCfg* net, const void* table_f16, const float* sigma_params,
+                         const NerfPointSrc* src, float* sigma /*[M]*/, float* x_hashtable /*[M,L*F] nullable*/, void* stream);
+int nerf_field_fwd_f16(const NerfGridCfg* grid, const NerfNetCfg* net, const void* table_f16, const float* sigma_params,
+                       const float* color_params, const float* latent_emb, int64_t n_images, const NerfPointSrc* src,
+                       float* sigma, float* rgb, float* x_hashtable, float* xyz, void* stream);
+int nerf_density_bwd_input_f16(const NerfGridCfg* grid, const NerfNetCfg* net, const void* table_f16,
+                               const float* sigma_params, const NerfPointSrc* src, const float* dsigma /*[M]*/,
+                               float* dx /*[M,3]*/, void* stream);
+int nerf_hashgrid_encode_levels_f16(const NerfGridCfg* grid, const void* table_f16, const NerfPointSrc* src,
+                                    const NerfLevelSet* levels, float* out, int64_t out_stride, void* stream);
 
 /* ---- hierarchical resampling ---- */
 /* renderer.py:154-160: alpha = 1-exp(-sigma*delta), exclusive transmittance, weights. zlog has

@@ -76,6 +76,12 @@ SIGNATURES = {
     'nerf_density_from_features': (_I, [_G, _N, _P, _P, _I64, _P, _P]),
     'nerf_field_from_features': (_I, [_G, _N, _P, _P, _P, _I64, _S, _P, _P, _P, _P, _P]),
     'nerf_feature_shuffle': (_I, [_P, _P, _I64, _I, C.POINTER(NerfColMap), _I, _P]),
+    'nerf_table_to_half': (_I, [_P, _P, _I64, _P]),
+    'nerf_hashgrid_fwd_f16': (_I, [_G, _P, _P, _I64, _P, _P]),
+    'nerf_density_fwd_f16': (_I, [_G, _N, _P, _P, _S, _P, _P, _P]),
+    'nerf_field_fwd_f16': (_I, [_G, _N, _P, _P, _P, _P, _I64, _S, _P, _P, _P, _P, _P]),
+    'nerf_density_bwd_input_f16': (_I, [_G, _N, _P, _P, _S, _P, _P, _P]),
+    'nerf_hashgrid_encode_levels_f16': (_I, [_G, _P, _S, _LS, _P, _I64, _P]),
     'nerf_coarse_weights': (_I, [_P, _P, _I64, _I64, _I, _P, _P]),
     'nerf_reweight': (_I, [_P, _I64, _I, _F, C.POINTER(C.c_int32), _I, _P, _P]),
     'nerf_sample_pdf': (_I, [_P, _I64, _P, _P, _P, _I64, _I, _I, _P, _P, _P, _P]),
@@ -173,7 +179,7 @@ def lib():
             fn.argtypes = args
             launches = res is _I and name not in ('nerf_abi_version',)
             setattr(l, name, _Timed(name, fn) if launches else fn)
-        if l.nerf_abi_version() != 3:
+        if l.nerf_abi_version() != 4:
             raise RuntimeError('libnerf_hip.so ABI version mismatch')
         _lib = l
     return _lib

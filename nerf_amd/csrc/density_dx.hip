@@ -12,7 +12,7 @@ int nerf_check_src(const char* fn, const NerfPointSrc* src, bool with_color);
 
 namespace {
 
-template <int F>
+template <int F, bool HALF = false>      // HALF: `table` is the half-precision gather copy (gather_level)
 __global__ __launch_bounds__(256) void density_dx_kernel(GridDev g, const float* __restrict__ table,
                                                          const float* __restrict__ sigma_w, NerfPointSrc src,
                                                          const float* __restrict__ dsigma, float* __restrict__ dx) {
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void density_dx_kernel(GridDev g, const float*
         LevelP lp = {g.scale[l], g.res[l], g.entries[l], g.hashed[l], g.offset[l], true};
         const Corners c = level_corners(lp, q.x, q.y, q.z);
         float feat[F];
-        gather_level<F>(table, c, feat);
+        gather_level<F, HALF>(table, c, feat);
 #pragma unroll
         for (int f = 0; f < F; ++f) {
             const float* w = W1 + (l * F + f) * kHid;
@@ -69,10 +69,12 @@ __global__ __launch_bounds__(256) void density_dx_kernel(GridDev g, const float*
         float ax = 0.f, ay = 0.f, az = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float* t = table + (size_t)c.idx[k] * F;
             float v = 0.f;
 #pragma unroll
-            for (int f = 0; f < F; ++f) v = fmaf(df[f], t[f], v);
+            for (int f = 0; f < F; ++f) {
+                const size_t e = (size_t)c.idx[k] * F + f;
+                v = fmaf(df[f], HALF ? (float)((const _Float16*)table)[e] : table[e], v);
+            }
             const float fx = (k & 1) ? wx : 1.f - wx, fy = (k & 2) ? wy : 1.f - wy, fz = (k & 4) ? wz : 1.f - wz;
             ax += ((k & 1) ? v : -v) * fy * fz;
             ay += ((k & 2) ? v : -v) * fx * fz;
@@ -90,9 +92,10 @@ __global__ __launch_bounds__(256) void density_dx_kernel(GridDev g, const float*
 
 }  // namespace
 
-extern "C" int nerf_density_bwd_input(const NerfGridCfg* grid, const NerfNetCfg* net, const float* table,
-                                      const float* sigma_params, const NerfPointSrc* src, const float* dsigma, float* dx,
-                                      void* stream) {
+template <bool HALF>
+static int density_bwd_input(const NerfGridCfg* grid, const NerfNetCfg* net, const float* table,
+                             const float* sigma_params, const NerfPointSrc* src, const float* dsigma, float* dx,
+                             void* stream) {
     int rc = nerf_check_cfg("nerf_density_bwd_input", grid, net, false);
     if (rc) return rc;
     rc = nerf_check_src("nerf_density_bwd_input", src, false);
@@ -107,7 +110,7 @@ extern "C" int nerf_density_bwd_input(const NerfGridCfg* grid, const NerfNetCfg*
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(FF)                                                                                                       \
     do {                                                                                                                 \
-        auto kern = density_dx_kernel<FF>;                                                                               \
+        auto kern = density_dx_kernel<FF, HALF>;                                                                             \
         static NerfLdsAttrCache lds_cache = {};   /* per instantiation */    \
         if (int e = nerf_ensure_dynamic_lds((const void*)kern, lds_bytes, &lds_cache, "density_bwd_input")) return e;    \
         kern<<<nb, 256, lds_bytes, st>>>(g, table, sigma_params, *src, dsigma, dx);                                      \
@@ -119,4 +122,16 @@ extern "C" int nerf_density_bwd_input(const NerfGridCfg* grid, const NerfNetCfg*
     }
 #undef LAUNCH
     return nerf_launch_status("nerf_density_bwd_input");
+}
+
+extern "C" int nerf_density_bwd_input(const NerfGridCfg* grid, const NerfNetCfg* net, const float* table,
+                                      const float* sigma_params, const NerfPointSrc* src, const float* dsigma, float* dx,
+                                      void* stream) {
+    return density_bwd_input<false>(grid, net, table, sigma_params, src, dsigma, dx, stream);
+}
+
+extern "C" int nerf_density_bwd_input_f16(const NerfGridCfg* grid, const NerfNetCfg* net, const void* table_f16,
+                                          const float* sigma_params, const NerfPointSrc* src, const float* dsigma, float* dx,
+                                          void* stream) {
+    return density_bwd_input<true>(grid, net, (const float*)table_f16, sigma_params, src, dsigma, dx, stream);
 }

@@ -242,11 +242,22 @@ __device__ __forceinline__ Corners level_corners(const LevelP& lp, float x, floa
     return c;
 }
 
-template <int F>
+// HALF: `table` is the half-precision gather copy of the table (the reference's `precision: float16`, nets.py:31-36,49:
+// tinycudann gathers from fp16 parameters beside an fp32 master): entries of F _Float16, widened on load, blended in fp32.
+template <int F, bool HALF = false>
 __device__ __forceinline__ void gather_level(const float* __restrict__ table, const Corners& c, float (&out)[F]) {
     float v[8][F];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
+        if (HALF) {
+            typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+            typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+            const _Float16* p = (const _Float16*)table + (size_t)c.idx[k] * F;
+            if (F == 1) v[k][0] = (float)p[0];
+            if (F == 2) { const h16x2 t = *(const h16x2*)p; v[k][0] = (float)t.x; v[k][F - 1] = (float)t.y; }
+            if (F == 4) { const h16x4 t = *(const h16x4*)p; v[k][0] = (float)t.x; v[k][1 % F] = (float)t.y; v[k][2 % F] = (float)t.z; v[k][3 % F] = (float)t.w; }
+            continue;
+        }
         const float* p = table + (size_t)c.idx[k] * F;
         if (F == 1) v[k][0] = p[0];
         if (F == 2) { f32x2 t = *(const f32x2*)p; v[k][0] = t.x; v[k][1] = t.y; }

@@ -16,7 +16,8 @@ constexpr int kFwdMaxThreads = NERF_FWD_THREADS;
 // One wavefront = 32 points x 2 lane halves; lane half h gathers levels [h*LH, h*LH + LH).
 // FEATS: the hash-grid features come ready-made from xh_in (level-sharded table: the level owners encoded
 // them and an all-to-all brought them here) instead of being gathered from `table`.
-template <int F, bool COLOR, bool FEATS>
+// HALF: `table` points at the half-precision gather copy (gather_level).
+template <int F, bool COLOR, bool FEATS, bool HALF = false>
 __global__ __launch_bounds__(kFwdMaxThreads) void field_fwd_kernel(GridDev g, NetLds s, const float* __restrict__ table,
                                                         const float* __restrict__ sigma_w,
                                                         const float* __restrict__ color_w,
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(kFwdMaxThreads) void field_fwd_kernel(GridDev g, Ne
                 else feat[0] = fsrc[0];
             } else {
                 const Corners c = level_corners(lp, q.x, q.y, q.z);
-                gather_level<F>(table, c, feat);
+                gather_level<F, HALF>(table, c, feat);
             }
 #pragma unroll
             for (int f = 0; f < F; ++f) {
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(kFwdMaxThreads) void field_fwd_kernel(GridDev g, Ne
 }
 
 // ---- stand-alone encodings (what tcnn.Encoding does when called on its own) ----
-template <int F>
+template <int F, bool HALF = false>
 __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(GridDev g, const float* __restrict__ table,
                                                            const float* __restrict__ x01, int64_t M,
                                                            float* __restrict__ out) {
@@ -167,13 +168,13 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(GridDev g, const floa
     LevelP lp = {g.scale[l], g.res[l], g.entries[l], g.hashed[l], g.offset[l], true};
     const Corners c = level_corners(lp, x01[p * 3], x01[p * 3 + 1], x01[p * 3 + 2]);
     float feat[F];
-    gather_level<F>(table, c, feat);
+    gather_level<F, HALF>(table, c, feat);
 #pragma unroll
     for (int f = 0; f < F; ++f) out[i * F + f] = feat[f];
 }
 
 // Encoding of a level subset for any point source: one thread per (point, level slot).
-template <int F>
+template <int F, bool HALF = false>
 __global__ __launch_bounds__(256) void encode_levels_kernel(GridDev g, const float* __restrict__ table, NerfPointSrc src,
                                                             NerfLevelSet set, float* __restrict__ out, int64_t stride) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(256) void encode_levels_kernel(GridDev g, const flo
     LevelP lp = {g.scale[l], g.res[l], g.entries[l], g.hashed[l], g.offset[l], true};
     const Corners c = level_corners(lp, q.x, q.y, q.z);
     float feat[F];
-    gather_level<F>(table, c, feat);
+    gather_level<F, HALF>(table, c, feat);
     float* dst = out + p * stride + slot * F;
     if (F == 2 && !(stride & 1) && !(((uintptr_t)out) & 7)) { f32x2 t; t.x = feat[0]; t.y = feat[F - 1]; *(f32x2*)dst = t; }
     else {
@@ -491,7 +492,7 @@ static int resident_blocks_per_cu(K kern, int threads, int lds_bytes) {
     return n;
 }
 
-template <bool COLOR, bool FEATS>
+template <bool COLOR, bool FEATS, bool HALF = false>
 static int launch_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const float* table, const float* sw, const float* cw,
                       const float* latent, int64_t n_images, const NerfPointSrc* src, float* sigma, float* rgb, float* xh,
                       float* xyz, const float* xh_in, void* stream) {
@@ -512,7 +513,7 @@ static int launch_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const floa
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(FF)                                                                                                     \
     do {                                                                                                               \
-        auto kern = field_fwd_kernel<FF, COLOR, FEATS>;                                                                     \
+        auto kern = field_fwd_kernel<FF, COLOR, FEATS, HALF>;                                                               \
         static NerfLdsAttrCache lds_cache = {};   /* per instantiation */    \
         if (int e = nerf_ensure_dynamic_lds((const void*)kern, lds_bytes, &lds_cache, "field_fwd")) return e;    \
         static int per_cu = 0, per_cu_lds = -1;     /* per instantiation; the net shape rarely changes */              \
@@ -531,8 +532,11 @@ static int launch_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const floa
 
 extern "C" {
 
-int nerf_density_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const float* table, const float* sigma_params,
-                     const NerfPointSrc* src, float* sigma, float* x_hashtable, void* stream) {
+}  // extern "C"
+
+template <bool HALF>
+static int density_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const float* table, const float* sigma_params,
+                       const NerfPointSrc* src, float* sigma, float* x_hashtable, void* stream) {
     int rc = nerf_check_cfg("nerf_density_fwd", grid, net, false);
     if (rc) return rc;
     rc = nerf_check_src("nerf_density_fwd", src, false);
@@ -540,13 +544,14 @@ int nerf_density_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const float
     NERF_REQUIRE(table && sigma_params && sigma, "null pointer");
     NERF_REQUIRE(!(src->ray_block && x_hashtable), "ray_block is for passes that keep no x_hashtable");
     if (src->n_points == 0) return 0;
-    return launch_fwd<false, false>(grid, net, table, sigma_params, nullptr, nullptr, 0, src, sigma, nullptr, x_hashtable,
-                                    nullptr, nullptr, stream);
+    return launch_fwd<false, false, HALF>(grid, net, table, sigma_params, nullptr, nullptr, 0, src, sigma, nullptr, x_hashtable,
+                                          nullptr, nullptr, stream);
 }
 
-int nerf_field_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const float* table, const float* sigma_params,
-                   const float* color_params, const float* latent_emb, int64_t n_images, const NerfPointSrc* src,
-                   float* sigma, float* rgb, float* x_hashtable, float* xyz, void* stream) {
+template <bool HALF>
+static int field_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const float* table, const float* sigma_params,
+                     const float* color_params, const float* latent_emb, int64_t n_images, const NerfPointSrc* src,
+                     float* sigma, float* rgb, float* x_hashtable, float* xyz, void* stream) {
     int rc = nerf_check_cfg("nerf_field_fwd", grid, net, true);
     if (rc) return rc;
     rc = nerf_check_src("nerf_field_fwd", src, true);
@@ -555,12 +560,13 @@ int nerf_field_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const float* 
     NERF_REQUIRE(net->latent_dim == 0 || (latent_emb && n_images > 0), "latent embedding missing");
     NERF_REQUIRE(!(src->ray_block && x_hashtable), "ray_block is for passes that keep no x_hashtable");
     if (src->n_points == 0) return 0;
-    return launch_fwd<true, false>(grid, net, table, sigma_params, color_params, latent_emb, n_images, src, sigma, rgb,
-                                   x_hashtable, xyz, nullptr, stream);
+    return launch_fwd<true, false, HALF>(grid, net, table, sigma_params, color_params, latent_emb, n_images, src, sigma, rgb,
+                                         x_hashtable, xyz, nullptr, stream);
 }
 
-int nerf_hashgrid_fwd(const NerfGridCfg* grid, const float* table, const float* x01, int64_t n_points, float* out,
-                      void* stream) {
+template <bool HALF>
+static int hashgrid_fwd(const NerfGridCfg* grid, const float* table, const float* x01, int64_t n_points, float* out,
+                        void* stream) {
     NERF_REQUIRE(grid && table && x01 && out, "null pointer");
     NERF_REQUIRE(n_points >= 0 && grid->total_entries < (1ull << 32), "bad sizes");
     if (n_points == 0) return 0;
@@ -568,12 +574,49 @@ int nerf_hashgrid_fwd(const NerfGridCfg* grid, const float* table, const float* 
     const unsigned nb = (unsigned)ceil_div64(n_points * g.L, 256);
     hipStream_t st = (hipStream_t)stream;
     switch (grid->n_features) {
-        case 1: hashgrid_fwd_kernel<1><<<nb, 256, 0, st>>>(g, table, x01, n_points, out); break;
-        case 2: hashgrid_fwd_kernel<2><<<nb, 256, 0, st>>>(g, table, x01, n_points, out); break;
-        case 4: hashgrid_fwd_kernel<4><<<nb, 256, 0, st>>>(g, table, x01, n_points, out); break;
+        case 1: hashgrid_fwd_kernel<1, HALF><<<nb, 256, 0, st>>>(g, table, x01, n_points, out); break;
+        case 2: hashgrid_fwd_kernel<2, HALF><<<nb, 256, 0, st>>>(g, table, x01, n_points, out); break;
+        case 4: hashgrid_fwd_kernel<4, HALF><<<nb, 256, 0, st>>>(g, table, x01, n_points, out); break;
         default: nerf_set_error("nerf_hashgrid_fwd: unsupported n_features"); return NERF_EUNSUPPORTED;
     }
     return nerf_launch_status("nerf_hashgrid_fwd");
+}
+
+extern "C" {
+
+int nerf_density_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const float* table, const float* sigma_params,
+                     const NerfPointSrc* src, float* sigma, float* x_hashtable, void* stream) {
+    return density_fwd<false>(grid, net, table, sigma_params, src, sigma, x_hashtable, stream);
+}
+
+int nerf_field_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const float* table, const float* sigma_params,
+                   const float* color_params, const float* latent_emb, int64_t n_images, const NerfPointSrc* src,
+                   float* sigma, float* rgb, float* x_hashtable, float* xyz, void* stream) {
+    return field_fwd<false>(grid, net, table, sigma_params, color_params, latent_emb, n_images, src, sigma, rgb, x_hashtable,
+                            xyz, stream);
+}
+
+int nerf_hashgrid_fwd(const NerfGridCfg* grid, const float* table, const float* x01, int64_t n_points, float* out,
+                      void* stream) {
+    return hashgrid_fwd<false>(grid, table, x01, n_points, out, stream);
+}
+
+/* ---- the same three with the half-precision gather copy of the table (precision: float16) ---- */
+int nerf_density_fwd_f16(const NerfGridCfg* grid, const NerfNetCfg* net, const void* table_f16, const float* sigma_params,
+                         const NerfPointSrc* src, float* sigma, float* x_hashtable, void* stream) {
+    return density_fwd<true>(grid, net, (const float*)table_f16, sigma_params, src, sigma, x_hashtable, stream);
+}
+
+int nerf_field_fwd_f16(const NerfGridCfg* grid, const NerfNetCfg* net, const void* table_f16, const float* sigma_params,
+                       const float* color_params, const float* latent_emb, int64_t n_images, const NerfPointSrc* src,
+                       float* sigma, float* rgb, float* x_hashtable, float* xyz, void* stream) {
+    return field_fwd<true>(grid, net, (const float*)table_f16, sigma_params, color_params, latent_emb, n_images, src, sigma,
+                           rgb, x_hashtable, xyz, stream);
+}
+
+int nerf_hashgrid_fwd_f16(const NerfGridCfg* grid, const void* table_f16, const float* x01, int64_t n_points, float* out,
+                          void* stream) {
+    return hashgrid_fwd<true>(grid, (const float*)table_f16, x01, n_points, out, stream);
 }
 
 static NerfLevelSet level_range(int begin, int count) {
@@ -716,8 +759,9 @@ extern "C" int nerf_hashgrid_scatter(const NerfGridCfg* grid, const NerfPointSrc
 }
 
 // ---- level-sharded table: the two halves of the fused calls, cut at the feature matrix ----
-extern "C" int nerf_hashgrid_encode_levels(const NerfGridCfg* grid, const float* table, const NerfPointSrc* src,
-                                           const NerfLevelSet* levels, float* out, int64_t out_stride, void* stream) {
+template <bool HALF>
+static int encode_levels(const NerfGridCfg* grid, const float* table, const NerfPointSrc* src,
+                         const NerfLevelSet* levels, float* out, int64_t out_stride, void* stream) {
     NERF_REQUIRE(grid && table && out, "null pointer");
     NERF_REQUIRE(grid->total_entries < (1ull << 32), "bad grid");
     int rc = nerf_check_src("nerf_hashgrid_encode_levels", src, false);
@@ -730,12 +774,22 @@ extern "C" int nerf_hashgrid_encode_levels(const NerfGridCfg* grid, const float*
     const unsigned nb = (unsigned)ceil_div64(src->n_points * levels->count, 256);
     hipStream_t st = (hipStream_t)stream;
     switch (grid->n_features) {
-        case 1: encode_levels_kernel<1><<<nb, 256, 0, st>>>(g, table, *src, *levels, out, out_stride); break;
-        case 2: encode_levels_kernel<2><<<nb, 256, 0, st>>>(g, table, *src, *levels, out, out_stride); break;
-        case 4: encode_levels_kernel<4><<<nb, 256, 0, st>>>(g, table, *src, *levels, out, out_stride); break;
+        case 1: encode_levels_kernel<1, HALF><<<nb, 256, 0, st>>>(g, table, *src, *levels, out, out_stride); break;
+        case 2: encode_levels_kernel<2, HALF><<<nb, 256, 0, st>>>(g, table, *src, *levels, out, out_stride); break;
+        case 4: encode_levels_kernel<4, HALF><<<nb, 256, 0, st>>>(g, table, *src, *levels, out, out_stride); break;
         default: nerf_set_error("nerf_hashgrid_encode_levels: unsupported n_features"); return NERF_EUNSUPPORTED;
     }
     return nerf_launch_status("nerf_hashgrid_encode_levels");
+}
+
+extern "C" int nerf_hashgrid_encode_levels(const NerfGridCfg* grid, const float* table, const NerfPointSrc* src,
+                                           const NerfLevelSet* levels, float* out, int64_t out_stride, void* stream) {
+    return encode_levels<false>(grid, table, src, levels, out, out_stride, stream);
+}
+
+extern "C" int nerf_hashgrid_encode_levels_f16(const NerfGridCfg* grid, const void* table_f16, const NerfPointSrc* src,
+                                               const NerfLevelSet* levels, float* out, int64_t out_stride, void* stream) {
+    return encode_levels<true>(grid, (const float*)table_f16, src, levels, out, out_stride, stream);
 }
 
 extern "C" int nerf_hashgrid_scatter_levels(const NerfGridCfg* grid, const NerfPointSrc* src, const NerfLevelSet* levels,

@@ -60,7 +60,34 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     }
 }
 
+// fp32 master table -> half-precision gather copy (round to nearest even; the reference's `precision: float16`,
+// nets.py:31-36,49: tinycudann keeps fp32 master parameters and gathers from their fp16 image).  A pure stream:
+// 4 B read + 2 B written per parameter.
+__global__ __launch_bounds__(256) void table_to_half_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, int64_t n) {
+    typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+    const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const f4 a = __builtin_nontemporal_load((const f4*)src + i);
+        h16x4 o;
+        o.x = (_Float16)a.x; o.y = (_Float16)a.y; o.z = (_Float16)a.z; o.w = (_Float16)a.w;
+        ((h16x4*)dst)[i] = o;
+    }
+    const int64_t tail = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tail < n) dst[tail] = (_Float16)src[tail];
+}
+
 }  // namespace
+
+extern "C" int nerf_table_to_half(const float* table, void* table_f16, int64_t count, void* stream) {
+    NERF_REQUIRE(count >= 0, "negative count");
+    if (count == 0) return 0;           // (an empty tensor has no address)
+    NERF_REQUIRE(table && table_f16, "null pointer");
+    NERF_REQUIRE((((uintptr_t)table) & 15) == 0 && (((uintptr_t)table_f16) & 7) == 0, "table must be 16-byte, its copy 8-byte aligned");
+    int64_t nb = ((count >> 2) + 255) / 256;
+    nb = nb < 1 ? 1 : (nb > 65536 ? 65536 : nb);
+    table_to_half_kernel<<<(unsigned)nb, 256, 0, (hipStream_t)stream>>>(table, (_Float16*)table_f16, count);
+    return nerf_launch_status("nerf_table_to_half");
+}
 
 extern "C" int nerf_adam_step_guarded(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t count, float lr,
                                       float beta1, float beta2, float eps, float weight_decay, int64_t step,

@@ -386,8 +386,10 @@ class LevelSharding(object):
     def _encode(self, table, kw, out, stride):
         from .nets import make_point_src
         src = make_point_src(**kw)
-        check(lib().nerf_hashgrid_encode_levels(C.byref(self.cfg), ptr(table), C.byref(src), C.byref(self.my_set), ptr(out),
-                                                stride, stream()), 'nerf_hashgrid_encode_levels')
+        enc = getattr(self, 'encoder', None)        # precision float16: gather from the half-precision image of the table
+        sfx, tab = enc.gather_table() if enc is not None and table.data_ptr() == enc.params.data_ptr() else ('', table)
+        check(getattr(lib(), 'nerf_hashgrid_encode_levels' + sfx)(C.byref(self.cfg), ptr(tab), C.byref(src), C.byref(self.my_set),
+                                                                  ptr(out), stride, stream()), 'nerf_hashgrid_encode_levels')
 
     # ---- forward: encode my levels for everybody, all-to-all, assemble [M, L*F] -------------
     def encode_exchange(self, table, src_all, m_local):

@@ -33,11 +33,18 @@ def make_point_src(outer_bound, x=None, d=None, n=None, rays_o=None, rays_d=None
 
 
 class HashGridEncoding(nn.Module):
-    """tcnn.Encoding{HashGrid} (nets.py:39-50): flat fp32 table, base_resolution 16, scale 1.3819."""
+    """tcnn.Encoding{HashGrid} (nets.py:39-50): flat fp32 table, base_resolution 16, scale 1.3819.
+
+    precision 'float16' (nets.py:31-36,49): the fp32 table stays the master copy that the optimizer updates -- as in
+    tinycudann's torch module -- and every kernel that READS the table gathers from a half-precision image of it
+    (`params_half`, refreshed by nerf_table_to_half whenever the master has changed since the last read)."""
 
     def __init__(self, n_levels, n_features_per_level, log2_hashmap_size, base_resolution=16, per_level_scale=1.3819,
-                 device='cuda', seed=None):
+                 device='cuda', seed=None, precision='float32'):
         super().__init__()
+        self.half = precision == 'float16'
+        self.params_half = None
+        self._half_state = None         # (version counter, data pointer) of the master the image was made from
         self.cfg = NerfGridCfg()
         total = lib().nerf_grid_cfg_init(C.byref(self.cfg), n_levels, n_features_per_level, log2_hashmap_size,
                                          base_resolution, per_level_scale)
@@ -51,6 +58,24 @@ class HashGridEncoding(nn.Module):
             g = torch.Generator(device='cpu').manual_seed(seed)
         init = (torch.rand(total * n_features_per_level, generator=g) * 2 - 1) * 1e-4
         self.params = nn.Parameter(init.to(device))
+        # optimizers that write through raw pointers (FusedAdam) cannot bump the tensor's version counter: they call this
+        self.params._nerf_after_update = self.mark_updated
+
+    def mark_updated(self):
+        self._half_state = None
+
+    def gather_table(self):
+        """(entry-point suffix, tensor) of what the forward kernels gather from: ('', fp32 table) or ('_f16', its image)."""
+        if not self.half:
+            return '', self.params
+        state = (self.params._version, self.params.data_ptr())
+        if self.params_half is None or self.params_half.device != self.params.device or self._half_state != state:
+            if self.params_half is None or self.params_half.device != self.params.device:
+                self.params_half = torch.empty(self.params.numel(), dtype=torch.float16, device=self.params.device)
+            check(lib().nerf_table_to_half(ptr(self.params), ptr(self.params_half), self.params.numel(), stream()),
+                  'nerf_table_to_half')
+            self._half_state = state
+        return '_f16', self.params_half
 
     def forward(self, x01):
         return _HashGridFn.apply(x01, self.params, self)
@@ -61,7 +86,8 @@ class _HashGridFn(torch.autograd.Function):
     def forward(ctx, x01, params, enc):
         x = f32(x01).reshape(-1, 3)
         out = torch.empty(x.shape[0], enc.n_output_dims, device=x.device, dtype=torch.float32)
-        check(lib().nerf_hashgrid_fwd(C.byref(enc.cfg), ptr(params), ptr(x), x.shape[0], ptr(out), stream()),
+        sfx, tab = enc.gather_table() if params is enc.params else ('', params)
+        check(getattr(lib(), 'nerf_hashgrid_fwd' + sfx)(C.byref(enc.cfg), ptr(tab), ptr(x), x.shape[0], ptr(out), stream()),
               'nerf_hashgrid_fwd')
         ctx.save_for_backward(x)
         ctx.enc = enc
@@ -185,9 +211,10 @@ class _FieldFn(torch.autograd.Function):
             # the count + scan passes of the binned table update, issued BEFORE the field kernel so that they run beside it
             ctx.count_tag = net.forward_count = getattr(net, 'forward_count', 0) + 1
             pipe.count_early(net.encoder.cfg, src, ctx.count_tag, dev)
-        check(lib().nerf_field_fwd(C.byref(net.encoder.cfg), C.byref(net.net_cfg), ptr(table), ptr(sigma_w), ptr(color_w),
-                                   ptr(lat), net.N, C.byref(src), ptr(sigma), ptr(rgb), ptr(xh), ptr(xyz), stream()),
-              'nerf_field_fwd')
+        sfx, tab = net.encoder.gather_table()
+        check(getattr(lib(), 'nerf_field_fwd' + sfx)(C.byref(net.encoder.cfg), C.byref(net.net_cfg), ptr(tab), ptr(sigma_w),
+                                                     ptr(color_w), ptr(lat), net.N, C.byref(src), ptr(sigma), ptr(rgb), ptr(xh),
+                                                     ptr(xyz), stream()), 'nerf_field_fwd')
         ctx.net, ctx.src_kwargs = net, src_kwargs
         ctx.save_for_backward(table, sigma_w, color_w, latent, xh)
         ctx.mark_non_differentiable(xh)
@@ -311,9 +338,11 @@ class _DensityInputGradFn(torch.autograd.Function):
         net = ctx.net
         src = make_point_src(ctx.outer_bound, x=xx, n_points=xx.shape[0])
         dx = torch.empty_like(xx)
-        check(lib().nerf_density_bwd_input(C.byref(net.encoder.cfg), C.byref(net.net_cfg), ptr(net.encoder.params),
-                                           ptr(net.sigma_net.params), C.byref(src), ptr(f32(dsigma).reshape(-1)), ptr(dx),
-                                           stream()), 'nerf_density_bwd_input')
+        sfx, tab = net.encoder.gather_table()
+        check(getattr(lib(), 'nerf_density_bwd_input' + sfx)(C.byref(net.encoder.cfg), C.byref(net.net_cfg), ptr(tab),
+                                                             ptr(net.sigma_net.params), C.byref(src),
+                                                             ptr(f32(dsigma).reshape(-1)), ptr(dx), stream()),
+              'nerf_density_bwd_input')
         return dx.reshape(ctx.shape), None, None
 
 
@@ -432,17 +461,17 @@ class NeRFNetwork(nn.Module):
                                                                                    sigma_num_layers, color_num_layers, geo_feat_dim))
         if encoding_dir_degree not in (0, 2, 4) or latent_embedding_dim % 2 or not 0 <= latent_embedding_dim <= 48:
             raise NotImplementedError('fused kernels need SH degree 0, 2 or 4 and an even latent_embedding_dim <= 48')
-        # precision: the reference's fp16 switch only changes tcnn's storage type; this build computes in
-        # fp32 (the CPU/fp32 semantics are the parity spec), so both values run fp32 -- said out loud
-        # once, not silently: a caller who asked for half precision gets MORE precision and an fp32-sized table.
-        if 'float16' in (encoding_precision, encoding_dir_precision if encoding_dir_degree != 0 else None):
+        # precision (nets.py:31-36): 'float16' for the hash grid = gathers from a half-precision image of the fp32 master
+        # table (HashGridEncoding); blends, MLPs, activations and optimizer state stay fp32 (the CPU/fp32 semantics are the
+        # parity spec).  The direction encoding has no table: its 'float16' only rounds tinycudann's output,
+        # here it is evaluated in fp32 -- said out loud once, not silently.
+        if encoding_dir_degree != 0 and encoding_dir_precision == 'float16':
             import warnings
-            warnings.warn("nerf_amd: encoding_precision / encoding_dir_precision 'float16' runs in float32 (tables, "
-                          "activations and optimizer state are fp32 in this build)", stacklevel=2)
-        self.encoding_precision = torch.float32
+            warnings.warn("nerf_amd: encoding_dir_precision 'float16' is evaluated in float32", stacklevel=2)
+        self.encoding_precision = torch.float16 if encoding_precision == 'float16' else torch.float32
         sd = (lambda k: None if seed is None else seed + k)
         self.encoder = HashGridEncoding(encoding_n_levels, encoding_n_features_per_level, encoding_log2_hashmap_size,
-                                        device=device, seed=sd(0))
+                                        device=device, seed=sd(0), precision=encoding_precision)
         self.sigma_net = FullyFusedMLP(self.encoder.n_output_dims, 1 + geo_feat_dim, sigma_hidden_dim,
                                        sigma_num_layers - 1, device=device, seed=sd(1))
         if encoding_dir_degree != 0:
@@ -510,6 +539,7 @@ class NeRFNetwork(nn.Module):
         """Shard the hash table by level over the process group (level_parallel.py)."""
         from .level_parallel import LevelSharding
         self.level_sharding = LevelSharding(self.encoder.cfg, self.encoder.params.device, owner=owner)
+        self.level_sharding.encoder = self.encoder      # (its encode passes gather from the encoder's half-precision image)
         return self.level_sharding
 
     def _sharded(self):
@@ -519,6 +549,7 @@ class NeRFNetwork(nn.Module):
     def sync_table(self):
         if self.level_sharding is not None:
             self.level_sharding.sync_table(self.encoder.params.data)
+            self.encoder.mark_updated()     # (broadcasts into .data do not bump the parameter's version counter)
 
     def local_table(self):
         """Context: make the local table whole (broadcast of the levels other ranks own, if stale) and run the
@@ -550,9 +581,11 @@ class NeRFNetwork(nn.Module):
             dev = self.encoder.params.device
             sigma = torch.empty(src.n_points, device=dev, dtype=torch.float32)
             rgb = torch.empty(src.n_points, 3, device=dev, dtype=torch.float32)
-            check(lib().nerf_field_fwd(C.byref(self.encoder.cfg), C.byref(self.net_cfg), ptr(self.encoder.params),
-                                       ptr(self.sigma_net.params), ptr(self.color_net.params), ptr(self.latent_emb), self.N,
-                                       C.byref(src), ptr(sigma), ptr(rgb), None, None, stream()), 'nerf_field_fwd')
+            sfx, tab = self.encoder.gather_table()
+            check(getattr(lib(), 'nerf_field_fwd' + sfx)(C.byref(self.encoder.cfg), C.byref(self.net_cfg), ptr(tab),
+                                                         ptr(self.sigma_net.params), ptr(self.color_net.params),
+                                                         ptr(self.latent_emb), self.N, C.byref(src), ptr(sigma), ptr(rgb),
+                                                         None, None, stream()), 'nerf_field_fwd')
         return sigma, rgb
 
     def forward(self, x, d, n, outer_bound):
@@ -603,7 +636,8 @@ class NeRFNetwork(nn.Module):
         dev = self.encoder.params.device
         sigma = torch.empty(src.n_points, device=dev, dtype=torch.float32)
         xh = torch.empty(src.n_points, self.encoder.n_output_dims, device=dev) if want_features else None
-        check(lib().nerf_density_fwd(C.byref(self.encoder.cfg), C.byref(self.net_cfg), ptr(self.encoder.params),
-                                     ptr(self.sigma_net.params), C.byref(src), ptr(sigma), ptr(xh), stream()),
+        sfx, tab = self.encoder.gather_table()
+        check(getattr(lib(), 'nerf_density_fwd' + sfx)(C.byref(self.encoder.cfg), C.byref(self.net_cfg), ptr(tab),
+                                                       ptr(self.sigma_net.params), C.byref(src), ptr(sigma), ptr(xh), stream()),
               'nerf_density_fwd')
         return sigma, xh

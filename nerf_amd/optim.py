@@ -359,6 +359,10 @@ class FusedAdam(torch.optim.Optimizer):
                 if early and p is not self._table_param:
                     continue
                 self._step_param(group, p)
+        for p in self._stepped:     # (parameters with a derived copy, e.g. the hash table's half-precision image)
+            cb = getattr(p, '_nerf_after_update', None)
+            if cb is not None:
+                cb()
         model = getattr(self, '_model', None)
         self._cleared_at = model.backward_count if model is not None else None
         if flag is not None:

@@ -237,6 +237,11 @@ class OracleNetwork(torch.nn.Module):
                  latent_embedding_dim=48, color_hidden_dim=64, color_num_layers=3, seed=0):
         super().__init__()
         self.N = N
+        # precision float16 (nets.py:31-36,49): tinycudann evaluates the encoding from the fp16 image of its fp32 master
+        # parameters; restated here as "the table is rounded to fp16 (nearest even) where it is gathered", gradients passing
+        # straight through to the master; the blend and everything after it stay fp32 (tinycudann's own fp16 blend
+        # arithmetic is absent from /root/reference and therefore unpinned)
+        self.half_table = encoding_precision == 'float16'
         self.n_levels = encoding_n_levels
         self.n_features = encoding_n_features_per_level
         self.levels, total = grid_levels(encoding_n_levels, encoding_log2_hashmap_size)
@@ -256,7 +261,10 @@ class OracleNetwork(torch.nn.Module):
         self.latent_emb = torch.nn.Parameter(torch.zeros(N, latent_embedding_dim))  # nets.py:90 zero init
 
     def encode(self, x01):
-        return hashgrid_encode(x01, self.encoder_params, self.levels, self.n_features)
+        table = self.encoder_params
+        if self.half_table:
+            table = table + (table.detach().half().float() - table.detach())
+        return hashgrid_encode(x01, table, self.levels, self.n_features)
 
     def forward(self, x, d, n, outer_bound):
         """nets.py:109-146."""

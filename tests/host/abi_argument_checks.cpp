@@ -81,6 +81,18 @@ int main() {
     EXPECT(nerf_hashgrid_scatter(&g, &rays, T, T, 18, 5, nullptr) != 0);          // levels 18..22 of 20
     EXPECT(nerf_hashgrid_fwd(&g, nullptr, T, 10, T, nullptr) == NERF_EINVAL);
     EXPECT(nerf_sh_fwd(T, 10, 3, T, nullptr) != 0);
+    // the half-precision table forms validate like the fp32 ones
+    NerfNetCfg bad16 = net;
+    bad16.hidden_dim = 32;
+    EXPECT(nerf_density_fwd_f16(&g, &bad16, T, T, &pts, T, nullptr, nullptr) == NERF_EUNSUPPORTED);
+    EXPECT(nerf_density_fwd_f16(&g, &net, nullptr, T, &pts, T, nullptr, nullptr) == NERF_EINVAL);
+    EXPECT(nerf_field_fwd_f16(&g, &net, T, T, T, nullptr, 0, &rays, T, T, nullptr, nullptr, nullptr) == NERF_EINVAL);
+    EXPECT(nerf_density_bwd_input_f16(&g, &net, T, T, &rays, T, T, nullptr) != 0);
+    EXPECT(nerf_hashgrid_fwd_f16(&g, nullptr, T, 10, T, nullptr) == NERF_EINVAL);
+    EXPECT(nerf_hashgrid_encode_levels_f16(&g, T, &pts, nullptr, T, 40, nullptr) == NERF_EINVAL);
+    EXPECT(nerf_table_to_half(nullptr, T, 16, nullptr) == NERF_EINVAL && nerf_table_to_half(T, T, -1, nullptr) == NERF_EINVAL);
+    EXPECT(nerf_table_to_half((const float*)T + 1, T, 16, nullptr) == NERF_EINVAL);         // misaligned
+    EXPECT(nerf_table_to_half(T, T, 0, nullptr) == 0);
 
     // ---- level sets of the sharded table and of the binned update ----
     NerfLevelSet ls = {};

@@ -31,7 +31,7 @@ def test_host_side_config_helpers():
     from nerf_amd import _lib
     from oracle.ref_cpu import grid_levels
     l = _lib.lib()
-    assert l.nerf_abi_version() == 3
+    assert l.nerf_abi_version() == 4
     for L, T in ((20, 24), (16, 19), (8, 15), (5, 14)):
         cfg = _lib.NerfGridCfg()
         total = l.nerf_grid_cfg_init(ctypes.byref(cfg), L, 2, T, 16, 1.3819)

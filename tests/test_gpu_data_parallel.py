@@ -34,12 +34,12 @@ def _batches():
     return out
 
 
-def _train(rank, world, log2_T=15):
+def _train(rank, world, log2_T=15, precision='float32'):
     from nerf_amd import helpers, parallel
     from nerf_amd.nets import NeRFNetwork
     from nerf_amd.optim import FusedAdam
     from nerf_amd.renderer import NerfRenderer
-    net = NeRFNetwork(5, seed=1, **dict(KW, encoding_log2_hashmap_size=log2_T))
+    net = NeRFNetwork(5, seed=1, **dict(KW, encoding_log2_hashmap_size=log2_T, encoding_precision=precision))
     with torch.no_grad():
         net.encoder.params.mul_(1e3)
     R = NerfRenderer(net, 2, 2.5, [1.6, 4.8], [64], 128, 0.2)
@@ -87,14 +87,14 @@ def _train(rank, world, log2_T=15):
     return [p.detach().cpu() for p in (net.encoder.params, net.sigma_net.params, net.color_net.params, net.latent_emb)]
 
 
-def _worker(rank, world, port, q, mode, log2_T, groups, prefetch=False):
+def _worker(rank, world, port, q, mode, log2_T, groups, prefetch=False, precision='float32'):
     os.environ['NERF_TABLE_PARALLEL'] = '1' if mode == 'sharded' else '0'
     os.environ['NERF_SHARD_GROUPS'] = str(groups)
     os.environ['NERF_TEST_PREFETCH'] = '1' if prefetch else '0'
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    out = _train(rank, world, log2_T)
+    out = _train(rank, world, log2_T, precision)
     if rank == 0:
         q.put([o.numpy() for o in out])
     dist.barrier()
@@ -105,7 +105,7 @@ def _worker(rank, world, port, q, mode, log2_T, groups, prefetch=False):
     ('dp', 2, 15, 1, False), ('sharded', 2, 15, 1, False), ('sharded', 3, 15, 1, False), ('sharded', 2, 19, 1, False),
     ('dp', 2, 19, 1, False), ('sharded', 2, 15, 3, False), ('sharded', 3, 19, 2, False), ('sharded', 2, 19, 4, True),
     ('sharded', 4, 19, 2, True)])
-def test_multi_rank_training_matches_single_process(mode, world, log2_T, groups, prefetch):
+def test_multi_rank_training_matches_single_process(mode, world, log2_T, groups, prefetch, precision='float32'):
     """world 3 puts a rank in the middle (remote points on both sides of its own block) and splits 8 levels 3/3/2.
     log2_T 19 makes levels 5-7 hashed and large: the single process and the level owners then take the binned table
     update (csrc/table_update.hip), the replicated 'dp' ranks the scatter -> all-reduce -> Adam pipeline.
@@ -119,15 +119,23 @@ def test_multi_rank_training_matches_single_process(mode, world, log2_T, groups,
     s.close()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode, log2_T, groups, prefetch)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode, log2_T, groups, prefetch, precision)) for r in range(world)]
     [p.start() for p in procs]
     got = q.get(timeout=150)
     [p.join(60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
-    want = _train(0, 1, log2_T)
+    want = _train(0, 1, log2_T, precision)
     for g, w, name in zip(got, want, ('table', 'sigma_net', 'color_net', 'latent')):
         # Adam divides by sqrt(v): elements whose gradient is ~0 amplify rounding differences between the two
         # reduction orders, so compare with an absolute bar at the scale of one update step (lr)
         torch.testing.assert_close(torch.from_numpy(g), w, rtol=0, atol=2e-3, msg=lambda m, n=name: n + ': ' + m)
         frac = float(((torch.from_numpy(g) - w).abs() > 1e-5).float().mean())
         assert frac < 0.02, (name, frac)
+
+
+@pytest.mark.parametrize('mode,world,groups', [('sharded', 2, 2), ('dp', 2, 1)])
+def test_multi_rank_training_with_half_precision_table(mode, world, groups):
+    """`precision: float16` (tests/test_gpu_half_table.py) under both multi-GPU table strategies: the level owners encode
+    from the half-precision image of THEIR levels (refreshed after their own update pass), the replicated ranks from the
+    image of the whole table; either way the result equals the single process with the same precision."""
+    test_multi_rank_training_matches_single_process(mode, world, 19, groups, mode == 'sharded', precision='float16')

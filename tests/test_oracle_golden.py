@@ -125,3 +125,24 @@ def test_inferencer_entry_points_vs_reference_golden():
     pts, col, var = ref_cpu.surface_geometry(g['weights'], g['z_vals'], g['xyzs'], g['rgbs'], 0.4, 0.1, 2)
     assert pts.shape[0] == 46
     assert torch.equal(pts, g['points']) and torch.equal(col, g['colors']) and torch.equal(var, g['depth_variance'])
+
+
+def test_oracle_float16_table_mode():
+    """`encoding_precision='float16'` of the oracle (nets.py:31-36,49; tinycudann's fp16 arithmetic itself is absent and
+    unpinned): the table is rounded to fp16 where it is gathered, the gradient goes straight through to the fp32 master."""
+    from oracle.ref_cpu import OracleNetwork
+    kw = dict(encoding_n_levels=6, encoding_log2_hashmap_size=12, latent_embedding_dim=0, encoding_dir_degree=0)
+    o16 = OracleNetwork(3, encoding_precision='float16', seed=1, **kw)
+    o32 = OracleNetwork(3, encoding_precision='float32', seed=1, **kw)
+    with torch.no_grad():
+        o16.encoder_params.mul_(1e3)
+        o32.encoder_params.copy_(o16.encoder_params.half().float())
+    assert o16.half_table and not o32.half_table
+    x = torch.rand(200, 3, generator=torch.Generator().manual_seed(2))
+    e16, e32 = o16.encode(x), o32.encode(x)
+    assert torch.equal(e16, e32)
+    w = torch.randn(200, e16.shape[1], generator=torch.Generator().manual_seed(3))
+    (e16 * w).sum().backward()
+    (e32 * w).sum().backward()
+    assert o16.encoder_params.grad is not None and torch.equal(o16.encoder_params.grad, o32.encoder_params.grad)
+    assert float((o16.encoder_params.detach() - o16.encoder_params.detach().half().float()).abs().max()) > 0     # master keeps its fp32 bits
