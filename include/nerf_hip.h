@@ -250,6 +250,17 @@ int nerf_density_bwd_input_f16(const NerfGridCfg* grid, const NerfNetCfg* net, c
                                float* dx /*[M,3]*/, void* stream);
 int nerf_hashgrid_encode_levels_f16(const NerfGridCfg* grid, const void* table_f16, const NerfPointSrc* src,
                                     const NerfLevelSet* levels, float* out, int64_t out_stride, void* stream);
+/* The optimizer passes that keep the image current themselves: nerf_adam_step_guarded / nerf_table_update_binned_guarded
+ * (train.py:84-88, trainer.py:134-138) with one more store per parameter, the new value rounded to nearest even into
+ * param_f16[i] / table_f16[i] (same index as the fp32 array; 8-byte aligned).  26 B per parameter instead of 24 B + a
+ * nerf_table_to_half pass of 6 B.  A dropped step (skip_flag) leaves the image untouched as well. */
+int nerf_adam_step_f16(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t count, float lr, float beta1,
+                       float beta2, float eps, float weight_decay, int64_t step, float grad_scale, int zero_grad,
+                       const double* skip_flag /* nullable */, void* param_f16, void* stream);
+int nerf_table_update_binned_f16(const NerfGridCfg* grid, const NerfLevelSet* levels, int64_t n_points, const void* workspace,
+                                 int64_t workspace_bytes, float* table, float* exp_avg, float* exp_avg_sq, float lr,
+                                 float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
+                                 const double* skip_flag /* nullable */, void* table_f16, void* stream);
 
 /* ---- hierarchical resampling ---- */
 /* renderer.py:154-160: alpha = 1-exp(-sigma*delta), exclusive transmittance, weights. zlog has

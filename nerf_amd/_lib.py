@@ -97,6 +97,8 @@ SIGNATURES = {
     'nerf_adam_step': (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _I64, _F, _I, _P]),
     'nerf_adam_step_guarded': (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _I64, _F, _I, _P, _P]),
     'nerf_table_update_binned_guarded': (_I, [_G, _LS, _I64, _P, _I64, _P, _P, _P, _F, _F, _F, _F, _F, _I64, _F, _P, _P]),
+    'nerf_adam_step_f16': (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _I64, _F, _I, _P, _P, _P]),
+    'nerf_table_update_binned_f16': (_I, [_G, _LS, _I64, _P, _I64, _P, _P, _P, _F, _F, _F, _F, _F, _I64, _F, _P, _P, _P]),
     'nerf_table_bin_workspace_bytes': (_I64, [_G, _LS, _I64]),
     'nerf_table_bin_levels': (_I, [_G, _S, _LS, _P, _I64, C.POINTER(C.c_int32), _P, _I64, _P]),
     'nerf_table_bin_count': (_I, [_G, _S, _LS, _P, _I64, _P]),

@@ -12,10 +12,14 @@ namespace {
 // `skip` (nullable): a device flag written earlier on the stream (nerf_losses' sums[5]: the step's loss was not finite).
 // When it is non-zero the pass only clears the gradient: parameters and moments stay as they are, which is what
 // GradScaler.step does with a non-finite gradient at trainer.py:134-136.
-template <bool ZERO>
+// HALF: the new parameters are also written, rounded to nearest even, into `ph` (the half-precision gather image of a
+// hash table slice, precision float16): same index as p.
+template <bool ZERO, bool HALF = false>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n, AdamK k,
-                                                   const double* __restrict__ skip) {
+                                                   const double* __restrict__ skip, _Float16* __restrict__ ph = nullptr) {
+    typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+    auto half4 = [](const f4& a) { h16x4 o; o.x = (_Float16)a.x; o.y = (_Float16)a.y; o.z = (_Float16)a.z; o.w = (_Float16)a.w; return o; };
     const int64_t n4 = n >> 2;
     if (skip && *skip != 0.0) {
         if (ZERO) {
@@ -43,11 +47,13 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
         adam4(pa, ga, ma, va, k);
         __builtin_nontemporal_store(pa, p4 + i0); __builtin_nontemporal_store(ma, m4 + i0);
         __builtin_nontemporal_store(va, v4 + i0);
+        if (HALF) ((h16x4*)ph)[i0] = half4(pa);
         if (ZERO) __builtin_nontemporal_store(zero, g4 + i0);
         if (two) {
             adam4(pb, gb, mb, vb, k);
             __builtin_nontemporal_store(pb, p4 + i1); __builtin_nontemporal_store(mb, m4 + i1);
             __builtin_nontemporal_store(vb, v4 + i1);
+            if (HALF) ((h16x4*)ph)[i1] = half4(pb);
             if (ZERO) __builtin_nontemporal_store(zero, g4 + i1);
         }
     }
@@ -56,6 +62,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
         float pp = p[tail], gg = g[tail], mm = m[tail], vv = v[tail];
         adam1(pp, gg, mm, vv, k);
         p[tail] = pp; m[tail] = mm; v[tail] = vv;
+        if (HALF) ph[tail] = (_Float16)pp;
         if (ZERO) g[tail] = 0.f;
     }
 }
@@ -89,10 +96,11 @@ extern "C" int nerf_table_to_half(const float* table, void* table_f16, int64_t c
     return nerf_launch_status("nerf_table_to_half");
 }
 
-extern "C" int nerf_adam_step_guarded(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t count, float lr,
-                                      float beta1, float beta2, float eps, float weight_decay, int64_t step,
-                                      float grad_scale, int zero_grad, const double* skip_flag, void* stream) {
+static int adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t count, float lr,
+                     float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                     float grad_scale, int zero_grad, const double* skip_flag, _Float16* param_f16, void* stream) {
     NERF_REQUIRE(param && grad && exp_avg && exp_avg_sq, "null pointer");
+    NERF_REQUIRE((((uintptr_t)param_f16) & 7) == 0, "the half-precision image must be 8-byte aligned");
     NERF_REQUIRE(count >= 0 && step >= 1, "bad count / step");
     NERF_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
                  "buffers must be 16-byte aligned");
@@ -101,9 +109,28 @@ extern "C" int nerf_adam_step_guarded(float* param, float* grad, float* exp_avg,
     int64_t want = ceil_div64(ceil_div64(count, 8), 256);
     if (want < 1) want = 1;
     const unsigned nb = (unsigned)(want < 65536 ? want : 65536);
-    if (zero_grad) adam_kernel<true><<<nb, 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, count, k, skip_flag);
-    else adam_kernel<false><<<nb, 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, count, k, skip_flag);
+    hipStream_t st = (hipStream_t)stream;
+    if (param_f16) {
+        if (zero_grad) adam_kernel<true, true><<<nb, 256, 0, st>>>(param, grad, exp_avg, exp_avg_sq, count, k, skip_flag, param_f16);
+        else adam_kernel<false, true><<<nb, 256, 0, st>>>(param, grad, exp_avg, exp_avg_sq, count, k, skip_flag, param_f16);
+    } else if (zero_grad) adam_kernel<true><<<nb, 256, 0, st>>>(param, grad, exp_avg, exp_avg_sq, count, k, skip_flag);
+    else adam_kernel<false><<<nb, 256, 0, st>>>(param, grad, exp_avg, exp_avg_sq, count, k, skip_flag);
     return nerf_launch_status("nerf_adam_step");
+}
+
+extern "C" int nerf_adam_step_guarded(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t count, float lr,
+                                      float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                                      float grad_scale, int zero_grad, const double* skip_flag, void* stream) {
+    return adam_step(param, grad, exp_avg, exp_avg_sq, count, lr, beta1, beta2, eps, weight_decay, step, grad_scale, zero_grad,
+                     skip_flag, nullptr, stream);
+}
+
+extern "C" int nerf_adam_step_f16(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t count, float lr,
+                                  float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
+                                  int zero_grad, const double* skip_flag, void* param_f16, void* stream) {
+    NERF_REQUIRE(param_f16 || count == 0, "null pointer");
+    return adam_step(param, grad, exp_avg, exp_avg_sq, count, lr, beta1, beta2, eps, weight_decay, step, grad_scale, zero_grad,
+                     skip_flag, (_Float16*)param_f16, stream);
 }
 
 extern "C" int nerf_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t count, float lr,

@@ -355,14 +355,17 @@ constexpr int kSubFloats = 4096;
 constexpr int kSubs = kPartFloats / kSubFloats;
 constexpr int kSplitThreads = 256;
 
-template <int F>
+// HALF: the new parameters are also written, rounded to nearest even, into the half-precision gather image of the table
+// (`ph`, same indexing as p; precision float16, nerf_hip.h): 26 B per parameter instead of 24 + a conversion pass of 6.
+template <int F, bool HALF = false>
 __global__ __launch_bounds__(kSplitThreads) void table_update_kernel(GridDev g, BinPlan plan,
                                                                      const uint32_t* __restrict__ bin_start,
                                                                      const uint16_t* __restrict__ item_idx,
                                                                      const float* __restrict__ item_val,
                                                                      int64_t n_items_level, float* __restrict__ p,
                                                                      float* __restrict__ m, float* __restrict__ v,
-                                                                     AdamK k, const double* __restrict__ skip) {
+                                                                     AdamK k, const double* __restrict__ skip,
+                                                                     _Float16* __restrict__ ph = nullptr) {
     static_assert(kSubFloats % (4 * kSplitThreads) == 0, "whole quads per thread");
     __shared__ __attribute__((aligned(16))) float acc[kSubFloats];
     if (skip && *skip != 0.0) return;       // non-finite loss this step (nerf_losses sums[5]): the step is dropped
@@ -471,6 +474,12 @@ __global__ __launch_bounds__(kSplitThreads) void table_update_kernel(GridDev g, 
             __builtin_nontemporal_store(pq[u], (f4*)p + base4 + ii);
             __builtin_nontemporal_store(mq[u], (f4*)m + base4 + ii);
             __builtin_nontemporal_store(vq[u], (f4*)v + base4 + ii);
+            if (HALF) {
+                typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+                h16x4 o;
+                o.x = (_Float16)pq[u].x; o.y = (_Float16)pq[u].y; o.z = (_Float16)pq[u].z; o.w = (_Float16)pq[u].w;
+                ((h16x4*)ph)[base4 + ii] = o;
+            }
         }
     }
 }
@@ -634,12 +643,13 @@ extern "C" int nerf_table_bin_fill_range(const NerfGridCfg* grid, const NerfPoin
                       workspace_bytes, stream, false, true, p_begin, p_end);
 }
 
-extern "C" int nerf_table_update_binned_guarded(const NerfGridCfg* grid, const NerfLevelSet* levels, int64_t n_points,
-                                                const void* workspace, int64_t workspace_bytes, float* table, float* exp_avg,
-                                                float* exp_avg_sq, float lr, float beta1, float beta2, float eps,
-                                                float weight_decay, int64_t step, float grad_scale, const double* skip_flag,
-                                                void* stream) {
+static int table_update_binned(const NerfGridCfg* grid, const NerfLevelSet* levels, int64_t n_points,
+                               const void* workspace, int64_t workspace_bytes, float* table, float* exp_avg,
+                               float* exp_avg_sq, float lr, float beta1, float beta2, float eps,
+                               float weight_decay, int64_t step, float grad_scale, const double* skip_flag,
+                               _Float16* table_f16, void* stream) {
     NERF_REQUIRE(grid && workspace && table && exp_avg && exp_avg_sq, "null pointer");
+    NERF_REQUIRE((((uintptr_t)table_f16) & 7) == 0, "the half-precision image must be 8-byte aligned");
     NERF_REQUIRE(step >= 1, "bad step");
     NERF_REQUIRE((((uintptr_t)table | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq | (uintptr_t)workspace) & 15) == 0,
                  "buffers must be 16-byte aligned");
@@ -657,8 +667,16 @@ extern "C" int nerf_table_update_binned_guarded(const NerfGridCfg* grid, const N
     hipStream_t st = (hipStream_t)stream;
     const unsigned nb = plan.part_base[plan.count];
 #define UPDATE(FF)                                                                                                     \
-    table_update_kernel<FF><<<nb * kSubs, kSplitThreads, 0, st>>>(g, plan, bin_start, item_idx, item_val, 8 * n_points, table,  \
-                                                                  exp_avg, exp_avg_sq, k, skip_flag)
+    do {                                                                                                               \
+        if (table_f16)                                                                                                 \
+            table_update_kernel<FF, true><<<nb * kSubs, kSplitThreads, 0, st>>>(g, plan, bin_start, item_idx, item_val, \
+                                                                                8 * n_points, table, exp_avg, exp_avg_sq, k, \
+                                                                                skip_flag, table_f16);                  \
+        else                                                                                                           \
+            table_update_kernel<FF><<<nb * kSubs, kSplitThreads, 0, st>>>(g, plan, bin_start, item_idx, item_val,      \
+                                                                          8 * n_points, table, exp_avg, exp_avg_sq, k, \
+                                                                          skip_flag);                                  \
+    } while (0)
     switch (grid->n_features) {
         case 1: UPDATE(1); break;
         case 2: UPDATE(2); break;
@@ -666,6 +684,25 @@ extern "C" int nerf_table_update_binned_guarded(const NerfGridCfg* grid, const N
     }
 #undef UPDATE
     return nerf_launch_status("nerf_table_update_binned");
+}
+
+extern "C" int nerf_table_update_binned_guarded(const NerfGridCfg* grid, const NerfLevelSet* levels, int64_t n_points,
+                                                const void* workspace, int64_t workspace_bytes, float* table, float* exp_avg,
+                                                float* exp_avg_sq, float lr, float beta1, float beta2, float eps,
+                                                float weight_decay, int64_t step, float grad_scale, const double* skip_flag,
+                                                void* stream) {
+    return table_update_binned(grid, levels, n_points, workspace, workspace_bytes, table, exp_avg, exp_avg_sq, lr, beta1,
+                               beta2, eps, weight_decay, step, grad_scale, skip_flag, nullptr, stream);
+}
+
+extern "C" int nerf_table_update_binned_f16(const NerfGridCfg* grid, const NerfLevelSet* levels, int64_t n_points,
+                                            const void* workspace, int64_t workspace_bytes, float* table, float* exp_avg,
+                                            float* exp_avg_sq, float lr, float beta1, float beta2, float eps,
+                                            float weight_decay, int64_t step, float grad_scale, const double* skip_flag,
+                                            void* table_f16, void* stream) {
+    NERF_REQUIRE(table_f16, "null pointer");
+    return table_update_binned(grid, levels, n_points, workspace, workspace_bytes, table, exp_avg, exp_avg_sq, lr, beta1,
+                               beta2, eps, weight_decay, step, grad_scale, skip_flag, (_Float16*)table_f16, stream);
 }
 
 extern "C" int nerf_table_update_binned(const NerfGridCfg* grid, const NerfLevelSet* levels, int64_t n_points,

@@ -12,6 +12,8 @@ from ._lib import NerfLevelSet, check, lib, ptr, stream
 
 
 SMALL_TENSORS_ON_SIDE_STREAM = os.environ.get('NERF_SMALL_ADAM_SIDE', '1') != '0'
+# precision float16: the table passes write the half-precision gather image themselves ('0': a conversion pass before the next forward)
+FUSED_HALF_IMAGE = os.environ.get('NERF_FUSED_HALF_IMAGE', '1') != '0'
 SPLIT_SMALL_GROUP = os.environ.get('NERF_SPLIT_SMALL', '1') != '0'
 
 
@@ -249,6 +251,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.skip_flag = None
         self.skipped_steps = 0        # steps found dropped so far (read back lazily, see _collect_flags)
         self._flag_reads = []         # (event, pinned host copy) of the flags of earlier steps
+        self._image_written = False   # this step's table passes wrote the half-precision image of the table themselves
         self._table_param = None
         self._pipeline = None
         self._sharding = None
@@ -337,6 +340,7 @@ class FusedAdam(torch.optim.Optimizer):
         flag = self.skip_flag
         self._skip_ptr = ptr(flag) if flag is not None else None
         self._stepped = []
+        self._image_written = False
         if self._flag_reads:
             self._collect_flags()
         # One GPU with the binned table update: the small tensors (MLPs, latent table) take their Adam step on the side
@@ -361,8 +365,9 @@ class FusedAdam(torch.optim.Optimizer):
                 self._step_param(group, p)
         for p in self._stepped:     # (parameters with a derived copy, e.g. the hash table's half-precision image)
             cb = getattr(p, '_nerf_after_update', None)
-            if cb is not None:
+            if cb is not None and not (p is self._table_param and self._image_written):
                 cb()
+        self._image_written = False
         model = getattr(self, '_model', None)
         self._cleared_at = model.backward_count if model is not None else None
         if flag is not None:
@@ -405,16 +410,37 @@ class FusedAdam(torch.optim.Optimizer):
             # no backward reached the table this step: the remaining (small) levels still take their Adam step
             flat_p, flat_g = p.view(-1), p.grad.view(-1)
             flat_m, flat_v = st['exp_avg'].view(-1), st['exp_avg_sq'].view(-1)
+            img = self._table_image(p)
             for (l0, cnt) in pipe.groups:
                 a, b = pipe.slices[l0]
-                self._adam(flat_p[a:b], flat_g[a:b], flat_m[a:b], flat_v[a:b], group, b1, b2, st['step'])
+                self._adam(flat_p[a:b], flat_g[a:b], flat_m[a:b], flat_v[a:b], group, b1, b2, st['step'],
+                           image=None if img is None else img[a:b])
             return
-        self._adam(p, p.grad, st['exp_avg'], st['exp_avg_sq'], group, b1, b2, st['step'])
+        self._adam(p, p.grad, st['exp_avg'], st['exp_avg_sq'], group, b1, b2, st['step'],
+                   image=self._table_image(p) if p is self._table_param else None)
 
-    def _adam(self, p, g, m, v, group, b1, b2, step):
+    def _adam(self, p, g, m, v, group, b1, b2, step, image=None):
+        """`image`: the slice of the hash table's half-precision gather image that mirrors `p` (precision float16): the pass
+        then writes it too."""
+        if image is not None:
+            check(lib().nerf_adam_step_f16(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), group['lr'], b1, b2, group['eps'],
+                                           group['weight_decay'], step, self.grad_scale, 1, getattr(self, '_skip_ptr', None),
+                                           ptr(image), stream()), 'nerf_adam_step')
+            return
         check(lib().nerf_adam_step_guarded(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), group['lr'], b1, b2, group['eps'],
                                            group['weight_decay'], step, self.grad_scale, 1, getattr(self, '_skip_ptr', None),
                                            stream()), 'nerf_adam_step')
+
+    def _table_image(self, p):
+        """The half-precision image of the table when the model gathers from one AND it mirrors the master right now: the
+        table passes of this step then keep it current themselves (26 B per parameter) instead of leaving it to a
+        conversion pass before the next forward.  None otherwise."""
+        enc = getattr(getattr(self, '_model', None), 'encoder', None)
+        if (enc is None or not getattr(enc, 'half', False) or p is not enc.params or enc.params_half is None
+                or enc._half_state != (p._version, p.data_ptr()) or not FUSED_HALF_IMAGE):
+            return None
+        self._image_written = True
+        return enc.params_half
 
     @torch.no_grad()
     def sync_sharded_state(self):
@@ -437,7 +463,15 @@ class FusedAdam(torch.optim.Optimizer):
         """The levels that go through the binned update: one pass that sums the step's corner updates per table
         partition in LDS and applies Adam (main stream; the small levels' scatter -> Adam runs beside it)."""
         cfg = self._model.encoder.cfg
-        if pipe.binned_pending is not None:
+        img = self._table_image(p)
+        if pipe.binned_pending is not None and img is not None:
+            n_points, nbytes = pipe.binned_pending
+            check(lib().nerf_table_update_binned_f16(C.byref(cfg), C.byref(pipe.binned_set), n_points, ptr(pipe.binned_ws),
+                                                     nbytes, ptr(p), ptr(st['exp_avg']), ptr(st['exp_avg_sq']), group['lr'],
+                                                     b1, b2, group['eps'], group['weight_decay'], st['step'],
+                                                     self.grad_scale, getattr(self, '_skip_ptr', None), ptr(img), stream()),
+                  'nerf_table_update_binned')
+        elif pipe.binned_pending is not None:
             n_points, nbytes = pipe.binned_pending
             check(lib().nerf_table_update_binned_guarded(C.byref(cfg), C.byref(pipe.binned_set), n_points, ptr(pipe.binned_ws),
                                                          nbytes, ptr(p), ptr(st['exp_avg']), ptr(st['exp_avg_sq']), group['lr'],
@@ -453,7 +487,8 @@ class FusedAdam(torch.optim.Optimizer):
             for l in pipe.binned_levels:
                 a = int(cfg.offset[l]) * F
                 b = a + int(cfg.entries[l]) * F
-                self._adam(flat_p[a:b], flat_g[a:b], flat_m[a:b], flat_v[a:b], group, b1, b2, st['step'])
+                self._adam(flat_p[a:b], flat_g[a:b], flat_m[a:b], flat_v[a:b], group, b1, b2, st['step'],
+                           image=None if img is None else img[a:b])
         pipe.drop_binned()
 
     def _pipelined_table_step(self, p, st, group, b1, b2, pipe):
@@ -462,6 +497,7 @@ class FusedAdam(torch.optim.Optimizer):
             pipe.side = torch.cuda.Stream()
         flat_p, flat_g = p.view(-1), p.grad.view(-1)
         flat_m, flat_v = st['exp_avg'].view(-1), st['exp_avg_sq'].view(-1)
+        img = self._table_image(p)
         with torch.cuda.stream(pipe.side):
             for (l0, cnt) in pipe.groups:
                 a, b = pipe.slices[l0]
@@ -471,6 +507,7 @@ class FusedAdam(torch.optim.Optimizer):
                 w = pipe.works.get(l0)
                 if w is not None:
                     w.wait()                      # side stream waits for the slice's all-reduce
-                self._adam(flat_p[a:b], flat_g[a:b], flat_m[a:b], flat_v[a:b], group, b1, b2, st['step'])
+                self._adam(flat_p[a:b], flat_g[a:b], flat_m[a:b], flat_v[a:b], group, b1, b2, st['step'],
+                           image=None if img is None else img[a:b])
         main.wait_stream(pipe.side)
         pipe.pending = False

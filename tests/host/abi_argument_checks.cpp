@@ -93,6 +93,9 @@ int main() {
     EXPECT(nerf_table_to_half(nullptr, T, 16, nullptr) == NERF_EINVAL && nerf_table_to_half(T, T, -1, nullptr) == NERF_EINVAL);
     EXPECT(nerf_table_to_half((const float*)T + 1, T, 16, nullptr) == NERF_EINVAL);         // misaligned
     EXPECT(nerf_table_to_half(T, T, 0, nullptr) == 0);
+    EXPECT(nerf_adam_step_f16(T, T, T, T, 16, 1e-2f, 0.9f, 0.99f, 1e-15f, 0.f, 1, 1.f, 1, nullptr, nullptr, nullptr) == NERF_EINVAL);
+    EXPECT(nerf_adam_step_f16(T, T, T, T, 16, 1e-2f, 0.9f, 0.99f, 1e-15f, 0.f, 0, 1.f, 1, nullptr, T, nullptr) == NERF_EINVAL);   // step 0
+    EXPECT(nerf_adam_step_f16(T, T, T, T, 16, 1e-2f, 0.9f, 0.99f, 1e-15f, 0.f, 1, 1.f, 1, nullptr, (char*)T + 2, nullptr) == NERF_EINVAL);
 
     // ---- level sets of the sharded table and of the binned update ----
     NerfLevelSet ls = {};
@@ -133,6 +136,8 @@ int main() {
     EXPECT(nerf_table_update_binned(&g, &ls, 524288, ws, ws_bytes, T, T, T, 1e-2f, .9f, .99f, 1e-15f, 0.f, 0, 1.f, nullptr) == NERF_EINVAL);
     EXPECT(nerf_table_update_binned(&g, &ls, 524288, ws, ws_bytes, fake<float>(0x1004), T, T, 1e-2f, .9f, .99f, 1e-15f, 0.f, 1, 1.f, nullptr) == NERF_EINVAL);
     EXPECT(nerf_table_update_binned(&g, &ls, 524288, ws, ws_bytes - 1, T, T, T, 1e-2f, .9f, .99f, 1e-15f, 0.f, 1, 1.f, nullptr) == NERF_EINVAL);
+    EXPECT(nerf_table_update_binned_f16(&g, &ls, 524288, ws, ws_bytes, T, T, T, 1e-2f, .9f, .99f, 1e-15f, 0.f, 1, 1.f, nullptr, nullptr, nullptr) == NERF_EINVAL);
+    EXPECT(nerf_table_update_binned_f16(&g, &ls, 524288, ws, ws_bytes - 1, T, T, T, 1e-2f, .9f, .99f, 1e-15f, 0.f, 1, 1.f, nullptr, T, nullptr) == NERF_EINVAL);
     EXPECT(nerf_hashgrid_encode_levels(&g, T, &rays, nullptr, T, 4, nullptr) != 0);
     ls.level[1] = 25;
     EXPECT(nerf_hashgrid_scatter_levels(&g, &rays, &ls, T, 4, T, nullptr) != 0);

@@ -155,12 +155,15 @@ def _batch(loader_seed, N, n_img=7):
     return n, h, w, K_all[n], E_all[n], torch.rand(3, generator=g), torch.rand(N, 128, generator=g), torch.rand(N, 3, generator=g)
 
 
-@pytest.mark.parametrize('name', ['small', 'base19'])
-def test_half_table_train_steps_vs_oracle(name):
+@pytest.mark.parametrize('name,fused', [('small', True), ('base19', True), ('base19', False)])
+def test_half_table_train_steps_vs_oracle(name, fused, monkeypatch):
     """Training with the half-precision image: fp32 master + fp32 Adam (FusedAdam; the binned update on 'base19'), the image
     refreshed after every step.  Loss trace against the oracle in float16 mode + torch.optim.Adam; the master must keep
-    what fp16 could not (updates below the fp16 spacing accumulate)."""
-    from nerf_amd import helpers
+    what fp16 could not (updates below the fp16 spacing accumulate).  fused: the table passes of FusedAdam write the image
+    themselves (nerf_table_update_binned_f16, nerf_adam_step_f16); otherwise a nerf_table_to_half pass runs before the next
+    forward.  Either way the image must be the rounding of the master, bit for bit, at every step."""
+    from nerf_amd import helpers, optim
+    monkeypatch.setattr(optim, 'FUSED_HALF_IMAGE', fused)
     from nerf_amd.optim import FusedAdam
     from nerf_amd.renderer import NerfRenderer
     from oracle import ref_cpu
@@ -191,6 +194,8 @@ def test_half_table_train_steps_vs_oracle(name):
         loss_g.backward()
         og.step()
         lg.append(float(loss_g))
+        # fused: the image was written by the optimizer's own passes and is still marked current (no conversion pass)
+        assert (n16.encoder._half_state is not None) == fused
         # the image in use at the NEXT forward is the rounding of the updated master
         _, tab = n16.encoder.gather_table()
         assert tab.dtype == torch.float16 and torch.equal(tab, n16.encoder.params.detach().half())
@@ -231,3 +236,32 @@ def test_half_image_follows_the_master_and_stays_out_of_checkpoints():
     before = n16.encoder._half_state
     n16.density(xc, 2.5)
     assert n16.encoder._half_state == before and n16.encoder.params_half.data_ptr() == img0.data_ptr()
+
+
+def test_half_image_under_the_non_finite_guard():
+    """A dropped step (non-finite loss, trainer.py:134-136) leaves master AND image untouched; the next good step moves both."""
+    from nerf_amd import helpers
+    from nerf_amd.optim import FusedAdam
+    from nerf_amd.renderer import NerfRenderer
+    n16, _, _ = _nets(CFGS['base19'])
+    R = NerfRenderer(n16, 2, 2.5, [1.6, 4.8], [64], 128, 0.2)
+    opt = FusedAdam([{'params': list(n16.encoder.parameters()) + [n16.latent_emb], 'lr': 2e-2},
+                     {'params': list(n16.sigma_net.parameters()) + list(n16.color_net.parameters()), 'lr': 1e-3}],
+                    betas=(0.9, 0.99), eps=1e-15).attach(n16)
+    n, h, w, K, E, bg, noise, gt = [t.cuda() for t in _batch(3, 64)]
+    for bad in (False, True, False):
+        before = n16.encoder.params.detach().clone()
+        opt.zero_grad()
+        img, wts, zs, _ = R.render(n, h, w, K, E, bg, noise=noise)
+        target = gt.clone()
+        if bad:
+            target[5, 1] = float('nan')
+        loss, _ = helpers.fused_train_loss(img, target, wts, zs, 1e-3, 1e-1)
+        opt.skip_flag = loss.nonfinite_flag
+        loss.backward()
+        opt.step()
+        torch.cuda.synchronize()
+        assert n16.encoder._half_state is not None          # written (or, when dropped, left alone) by the table passes
+        _, tab = n16.encoder.gather_table()
+        assert torch.equal(tab, n16.encoder.params.detach().half())
+        assert torch.equal(before, n16.encoder.params.detach()) == bad
