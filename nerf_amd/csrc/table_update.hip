@@ -29,7 +29,10 @@ constexpr int kPartFloats = NERF_PART_FLOATS;   // floats of one table partition
 #define NERF_BIN_CHUNK 16384
 #endif
 constexpr int kBinChunkPts = NERF_BIN_CHUNK;   // points per workgroup of the count / fill passes
-constexpr int kBinThreads = 1024;
+#ifndef NERF_BIN_THREADS
+#define NERF_BIN_THREADS 1024
+#endif
+constexpr int kBinThreads = NERF_BIN_THREADS;      // threads of a count / scan / fill workgroup (512: two fill workgroups per CU, 0.63 vs 0.55 ms -- DESIGN.md "tried")
 #ifndef NERF_MAX_BINS
 #define NERF_MAX_BINS 8192
 #endif

@@ -9,6 +9,6 @@ for i in $(seq 1 ${ROUNDS:-2}); do for V in ${VARIANTS:-base}; do
 import json
 d = json.loads(open('$O/bench_${V}_$i.json').read().strip().splitlines()[-1])
 k = {x['name']: x['avg_launch_ms'] for x in d['kernels']}
-print('$V', round(d['ms_per_step'], 4), ' '.join('%s %.4f' % (n.replace('nerf_', ''), k[n]) for n in ('nerf_density_fwd', 'nerf_field_fwd', 'nerf_field_bwd', 'nerf_table_bin_fill', 'nerf_table_update_binned') if n in k), d.get('render', {}).get('ms_per_image'))
+print('$V', round(d['ms_per_step'], 4), ' '.join('%s %.4f' % (n.replace('nerf_', ''), k[n]) for n in ('nerf_density_fwd', 'nerf_field_fwd', 'nerf_field_bwd', 'nerf_table_bin_fill', 'nerf_table_update_binned') if n in k), (d.get('render') or {}).get('ms_per_image'))
 PY
 done; done
