@@ -481,7 +481,12 @@ def main():
                     'mfma_busy': mfma_counter(k['name']), 'avg_launch_ms': k['avg_launch_ms'],
                     'launches_per_step': k['launches_per_step'],
                     'algorithmic_flops_per_launch': algorithmic_flops('nerf_field_bwd', args.rays, Sc=sum(STEPS))
-                    / max(1.0, k['launches_per_step'])}
+                    / max(1.0, k['launches_per_step']),
+                    'note': ('algorithmic fp32 flops priced against the f32-input MFMA peak.  Two thirds of them (forward '
+                             'recompute + back-propagation chains) run on v_mfma_f32_32x32x2_f32; the weight-gradient third '
+                             'runs on v_mfma_f32_32x32x16_bf16 with split hi/lo operands (two MFMAs = four bf16 products per '
+                             'fp32 product, 4x fewer matrix-core cycles than the f32-input form), so frac is not a busy '
+                             'fraction: mfma_busy.util (counter pass) is, and it counts both kinds')}
         return {'kernel': k['name'], 'bound': 'hbm', 'achieved': k.get('algorithmic_GBps'), 'peak': HBM_PEAK_GBS,
                 'unit': 'GB/s', 'frac': k.get('hbm_frac'), 'traffic': rec['hbm_bytes'] if rec else None,
                 'traffic_source': (('committed PMC passes, not this run: profiles/traffic.json (build %s; rocprofv3 --pmc FETCH_SIZE '

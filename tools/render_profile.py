@@ -1,38 +1,39 @@
-#!/usr/bin/env python3
-"""render_image of one 800x800 view of the bench scene, a few times: the program to put under
-`rocprofv3 --kernel-trace --stats` for the inference path (inference.py:54-94).
-
-    python tools/render_profile.py [reps] [rays per chunk]
-"""
-import json
+"""Kernel timing of one 800 x 800 render_image (coherent traversal, 65 536-ray chunks) on the metric network: which kernels
+the 68 ms are made of.  Run under `rocprofv3 --kernel-trace --stats` or alone (prints the library's own per-entry-point timing)."""
 import os
 import sys
 import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 
 def main():
-    from nerf_amd.inference import Inferencer
-    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-    chunk = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
     dev = torch.device('cuda', 0)
-    model, renderer, loader, opt = bench.build_gpu(dev, 0, 4096)
-    for it in range(int(os.environ.get('TRAIN_STEPS', '20'))):
-        bench.train_step(model, renderer, loader, opt, 4096, it, 1)
-    inf = Inferencer(renderer, chunk, 0, 0, 0.1, 0.05, 0.4, [1, 2, 3, 4], 20)
+    torch.cuda.set_device(dev)
+    prec = sys.argv[1] if len(sys.argv) > 1 else 'float32'
+    bench.NET['encoding_precision'] = prec
+    model, renderer, loader, opt = bench.build_gpu(dev, 0, 4096, pipeline=True)
+    from nerf_amd.inference import Inferencer
+    from nerf_amd import _lib
+    inf = Inferencer(renderer, 65536, 0, 0, 0.1, 0.05, 0.4, [1, 2, 3, 4], 20)
     n, h, w, K, E, _, _, _ = loader.get_image_batch(0)
-    inf.render_image(n, h, w, K, E)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
+    for _ in range(2):
         inf.render_image(n, h, w, K, E)
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
-    print(json.dumps({'rays': int(n.numel()), 'chunk': chunk, 'ms_per_image': dt * 1e3, 'rays_per_s': n.numel() / dt}))
+    _lib.kernel_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        inf.render_image(n, h, w, K, E)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    rows = _lib.kernel_timing(False)
+    print('%s: %.2f ms per image' % (prec, dt * 1e3))
+    for name, (calls, ms) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
+        print('  %-34s %4d calls  %8.3f ms per image' % (name, calls // 3, ms / 3))
 
 
 if __name__ == '__main__':
