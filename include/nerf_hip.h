@@ -286,6 +286,14 @@ int nerf_coarse_to_fine(const float* sigma, const float* zlog, int64_t zlog_stri
 int nerf_coarse_to_fine_rng(const float* sigma, const float* zlog, int64_t zlog_stride, uint64_t seed, uint64_t counter,
                             const float* lin, int64_t n_rays, int n_samples, int n_importance, float alpha,
                             const int32_t* steps, int n_segments, float* zlog_fine, float* z_fine, void* stream);
+/* The same for rays [first_ray, first_ray + n_rays) of a batch (sigma, zlog rows and outputs are those of the slice): the
+ * noise is element (first_ray + ray) * n_importance + k of the stream, so a batch resampled slice by slice -- the ray
+ * groups of the level-sharded step, which start each group's depth all-gather while the next group is still in its
+ * coarse pass -- draws exactly what one launch over the whole batch draws. */
+int nerf_coarse_to_fine_rng_at(const float* sigma, const float* zlog, int64_t zlog_stride, uint64_t seed, uint64_t counter,
+                               int64_t first_ray, const float* lin, int64_t n_rays, int n_samples, int n_importance,
+                               float alpha, const int32_t* steps, int n_segments, float* zlog_fine, float* z_fine,
+                               void* stream);
 int nerf_uniform_noise(uint64_t seed, uint64_t counter, int64_t n, float* out, void* stream);
 
 /* ---- alpha compositing: renderer.py:71-85 (render_rays_log) + :181-182 ---- */

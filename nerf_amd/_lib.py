@@ -88,6 +88,8 @@ SIGNATURES = {
     'nerf_coarse_to_fine': (_I, [_P, _P, _I64, _P, _P, _I64, _I, _I, _F, C.POINTER(C.c_int32), _I, _P, _P, _P]),
     'nerf_coarse_to_fine_rng': (_I, [_P, _P, _I64, C.c_uint64, C.c_uint64, _P, _I64, _I, _I, _F, C.POINTER(C.c_int32), _I, _P, _P,
                                      _P]),
+    'nerf_coarse_to_fine_rng_at': (_I, [_P, _P, _I64, C.c_uint64, C.c_uint64, _I64, _P, _I64, _I, _I, _F, C.POINTER(C.c_int32), _I, _P, _P,
+                                     _P]),
     'nerf_uniform_noise': (_I, [C.c_uint64, C.c_uint64, _I64, _P, _P]),
     'nerf_composite_fwd': (_I, [_P, _P, _P, _P, _P, _I64, _I, _F, _F, _P, _P, _P, _P, _P]),
     'nerf_composite_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I64, _I, _P, _P, _P]),

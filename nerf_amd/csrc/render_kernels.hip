@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void ray_sampling_kernel(const float* __restri
                                                            const float* __restrict__ lin, int64_t n_rays, int S, int Sf,
                                                            float alpha_over_s, SegCfg seg, float* __restrict__ out_a,
                                                            float* __restrict__ out_b, int64_t* __restrict__ inds,
-                                                           uint64_t seed, uint64_t counter) {
+                                                           uint64_t seed, uint64_t counter, uint64_t first_ray = 0) {
     extern __shared__ float s_rows[];       // MODE 2 / 3: [kRaysPerBlock][2][S]
     constexpr int W = VecW<C>::W;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -408,7 +408,8 @@ __global__ __launch_bounds__(256) void ray_sampling_kernel(const float* __restri
                             [&](int k, float (&nz)[2]) { nz[0] = nrow[k]; nz[1] = k + 1 < Sf ? nrow[k + 1] : 0.f; }, lin, Sf,
                             out_a + ray * Sf, out_b ? out_b + ray * Sf : nullptr, inds ? inds + ray * Sf : nullptr, pair_stores);
     } else {
-        const uint64_t e0 = (uint64_t)ray * (uint64_t)Sf;
+        // (first_ray: this launch covers rays [first_ray, first_ray + n_rays) of the batch the noise stream belongs to)
+        const uint64_t e0 = (first_ray + (uint64_t)ray) * (uint64_t)Sf;
         stage_sample_pdf<C>(pdf, zl, cdf_s, zl_s, S, lane,
                             [&](int k, float (&nz)[2]) { philox_uniform2(seed, counter, e0 + (uint64_t)k, nz[0], nz[1]); }, lin, Sf,
                             out_a + ray * Sf, out_b ? out_b + ray * Sf : nullptr, inds ? inds + ray * Sf : nullptr, pair_stores);
@@ -1040,7 +1041,9 @@ int nerf_sample_pdf(const float* zlog, int64_t zlog_stride, const float* pdf, co
 
 static int coarse_to_fine(const char* fn, const float* sigma, const float* zlog, int64_t zlog_stride, const float* noise,
                           uint64_t seed, uint64_t counter, const float* lin, int64_t n_rays, int n_samples, int n_importance,
-                          float alpha, const int32_t* steps, int n_segments, float* zlog_fine, float* z_fine, void* stream) {
+                          float alpha, const int32_t* steps, int n_segments, float* zlog_fine, float* z_fine, void* stream,
+                          int64_t first_ray = 0) {
+    if (first_ray < 0) { nerf_set_error("%s: negative first_ray", fn); return NERF_EINVAL; }
     if (!(sigma && zlog && lin && steps && zlog_fine)) { nerf_set_error("%s: null pointer", fn); return NERF_EINVAL; }
     if (n_samples < 4 || n_samples > kMaxS) { nerf_set_error("%s: n_samples must be in [4, 512]", fn); return NERF_EINVAL; }
     if (n_importance < 1) { nerf_set_error("%s: n_importance must be positive", fn); return NERF_EINVAL; }
@@ -1052,7 +1055,7 @@ static int coarse_to_fine(const char* fn, const float* sigma, const float* zlog,
     row_dispatch(row_shape(n_samples, zlog_stride, {sigma, zlog}), [&](auto c_, auto v_) {
         ray_sampling_kernel<3, ROW_C, ROW_V><<<(unsigned)ceil_div64(n_rays, kRaysPerBlock), 256, lds, S_(stream)>>>(
             sigma, zlog, zlog_stride, noise, lin, n_rays, n_samples, n_importance,
-            (float)((double)alpha / (double)n_samples), seg, zlog_fine, z_fine, nullptr, seed, counter);
+            (float)((double)alpha / (double)n_samples), seg, zlog_fine, z_fine, nullptr, seed, counter, (uint64_t)first_ray);
     });
     return nerf_launch_status(fn);
 }
@@ -1070,6 +1073,13 @@ int nerf_coarse_to_fine_rng(const float* sigma, const float* zlog, int64_t zlog_
                             const int32_t* steps, int n_segments, float* zlog_fine, float* z_fine, void* stream) {
     return coarse_to_fine("nerf_coarse_to_fine_rng", sigma, zlog, zlog_stride, nullptr, seed, counter, lin, n_rays, n_samples,
                           n_importance, alpha, steps, n_segments, zlog_fine, z_fine, stream);
+}
+
+int nerf_coarse_to_fine_rng_at(const float* sigma, const float* zlog, int64_t zlog_stride, uint64_t seed, uint64_t counter,
+                               int64_t first_ray, const float* lin, int64_t n_rays, int n_samples, int n_importance, float alpha,
+                               const int32_t* steps, int n_segments, float* zlog_fine, float* z_fine, void* stream) {
+    return coarse_to_fine("nerf_coarse_to_fine_rng_at", sigma, zlog, zlog_stride, nullptr, seed, counter, lin, n_rays, n_samples,
+                          n_importance, alpha, steps, n_segments, zlog_fine, z_fine, stream, first_ray);
 }
 
 int nerf_uniform_noise(uint64_t seed, uint64_t counter, int64_t n, float* out, void* stream) {

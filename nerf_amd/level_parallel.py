@@ -186,6 +186,7 @@ class LevelSharding(object):
         self._colmaps = {}
         self._group_perm = {}
         self._prefetched = None  # (rays_o, rays_d, packed source, gathered rows, work) of prefetch_rays
+        self._pregathered = None # per-group all-gathers of the fine pass's rays + depths, started from the coarse pass
         self.force = False      # run the exchange code even in a world of one rank (exercises the RCCL calls on one GPU)
         self.dirty = False      # True once an optimizer step made the non-owned levels of the local table stale
 
@@ -264,6 +265,47 @@ class LevelSharding(object):
         # profiles/r02h_shard_*.log); four groups lose more to the smaller launches than they hide
         return 2
 
+    def cuts_for(self, rows, n_points, groups=None):
+        """The ray groups [(first ray, end ray)] plan() cuts a batch of `rows` rays / `n_points` sample points into."""
+        groups = groups or self.n_groups(n_points)
+        if isinstance(groups, (list, tuple)):
+            edges, acc = [0], 0.0
+            for f in groups[:-1]:
+                acc += f / float(sum(groups))
+                edges.append(min(rows, max(edges[-1], int(round(acc * rows)))))
+            edges.append(rows)
+            return [(a, b) for a, b in zip(edges[:-1], edges[1:]) if b > a] or [(0, rows)]
+        G = max(1, min(int(groups), max(rows, 1)))
+        return [parallel.shard_range(rows, g, G) for g in range(G)]
+
+    # ---- fine-pass depths gathered group by group, from inside the coarse pass ---------------------------------
+    # The fine pass needs the rays AND resampled depths of all ranks; the depths exist only after the coarse pass, so their
+    # all-gather stood, for its whole latency, between the two passes.  With ray groups the renderer resamples group g as
+    # soon as its coarse densities exist and starts the all-gather of that group's rows at once: it completes under the
+    # coarse pass of group g+1 (or, for the last group, under the fine encode of group 0) and plan() picks the rows up.
+    def _drop_pregathered(self):
+        pg, self._pregathered = self._pregathered, None
+        if pg is not None:
+            for part in pg['parts']:
+                if part is not None and part[2] is not None:
+                    part[2].wait()      # let an all-gather nobody asked for finish before its buffers go away
+
+    def pregather_start(self, rows, cuts):
+        self._drop_pregathered()
+        return {'rows': rows, 'cuts': list(cuts), 'parts': [None] * len(cuts), 'z': None}
+
+    def pregather_group(self, st, g, rays_o, rays_d, z):
+        """Start the all-gather of group g's rows [rays_o | rays_d | z] (this rank's rays [ra, rb) of the batch)."""
+        packed = torch.cat([rays_o, rays_d, z], 1)
+        out, work = parallel.all_gather_rows(packed, async_op=True)
+        st['parts'][g] = (packed, out, work)
+
+    def pregather_finish(self, st, z):
+        """`z`: the [rows, S] depth tensor the fine pass will be called with (its identity is the key)."""
+        st['z'] = z
+        self._pregathered = st
+        self.pregather_count = getattr(self, 'pregather_count', 0) + 1
+
     def plan(self, kw, groups=None):
         """Gather the point source of every rank (one all-gather, as gather_src) and cut it into ray groups.
         The gathered rays are kept GROUP-major ([group][rank][ray]) so that the points of all ranks of one group are
@@ -273,25 +315,24 @@ class LevelSharding(object):
         unit = int(kw['n_samples']) if rays else 1
         M = int(kw['n_points'])
         rows = M // unit
-        groups = groups or self.n_groups(M)
         W = self.world
-        if isinstance(groups, (list, tuple)):
-            edges, acc = [0], 0.0
-            for f in groups[:-1]:
-                acc += f / float(sum(groups))
-                edges.append(min(rows, max(edges[-1], int(round(acc * rows)))))
-            edges.append(rows)
-            cuts = [(a, b) for a, b in zip(edges[:-1], edges[1:]) if b > a] or [(0, rows)]
-        else:
-            G = max(1, min(int(groups), max(rows, 1)))
-            cuts = [parallel.shard_range(rows, g, G) for g in range(G)]
+        cuts = self.cuts_for(rows, M, groups)
         G = len(cuts)
-        whole = self.gather_src(kw) if G == 1 else self._gather_group_major(kw, cuts, rows)
+        ready = None
+        if G == 1:
+            if self._pregathered is not None:
+                self._drop_pregathered()
+            whole = self.gather_src(kw)
+        else:
+            whole, ready = self._gather_group_major(kw, cuts, rows)
         out = []
-        for (ra, rb) in cuts:
+        for gi, (ra, rb) in enumerate(cuts):
             grp = {'ra': ra, 'rb': rb, 'a': ra * unit, 'b': rb * unit, 'm': (rb - ra) * unit}
             grp['kw_local'] = _slice_rows(kw, ra, rb, unit)
             grp['kw_all'] = whole if G == 1 else _slice_rows(whole, W * ra, W * rb, unit)
+            # (pre-gathered depths: the rows of this group in `whole` are filled by this call, on the current stream, right
+            # before the group's first use -- encode_exchange_groups -- so that a later group's all-gather is not waited for early)
+            grp['ready'] = ready[gi] if ready is not None else None
             out.append(grp)
         return {'groups': out, 'kw_all': whole, 'm_local': M, 'unit': unit}
 
@@ -303,13 +344,40 @@ class LevelSharding(object):
             idx = [q * rows + i for (ra, rb) in cuts for q in range(W) for i in range(ra, rb)]
             perm = self._group_perm[key] = torch.tensor(idx, dtype=torch.int64, device=self.perm.device)
         out = dict(outer_bound=kw['outer_bound'], inner_bound=kw.get('inner_bound', 0.0))
+        pg = self._pregathered
         if kw.get('x') is not None:
+            if pg is not None:
+                self._drop_pregathered()
             x = parallel.all_gather_rows(kw['x']).index_select(0, perm.to(kw['x'].device))
             out.update(x=x, n_points=x.shape[0])
-            return out
+            return out, None
         ro, rd = kw['rays_o'], kw['rays_d']
         S, zs = kw['n_samples'], kw.get('z_stride', 0)
         perm = perm.to(ro.device)
+        if zs != 0 and pg is not None and pg['z'] is kw['z'] and pg['cuts'] == list(cuts) and pg['rows'] == rows:
+            # the groups' rows were gathered from inside the coarse pass (pregather_group): a group's gathered block
+            # [rank][ray of the group] IS its stretch of the group-major order -- no collective and no permutation here
+            self._pregathered = None
+            self.pregather_hits = getattr(self, 'pregather_hits', 0) + 1
+            ro_all = ro.new_empty(W * rows, 3)
+            rd_all = ro.new_empty(W * rows, 3)
+            z_all = ro.new_empty(W * rows, zs)
+            parts = pg['parts']
+
+            def make_ready(gi, ra, rb):
+                def ready():
+                    _packed, got, work = parts[gi]
+                    if work is not None:
+                        work.wait()
+                    ro_all[W * ra:W * rb].copy_(got[:, 0:3])
+                    rd_all[W * ra:W * rb].copy_(got[:, 3:6])
+                    z_all[W * ra:W * rb].copy_(got[:, 6:])
+                    parts[gi] = None
+                return ready
+            out.update(rays_o=ro_all, rays_d=rd_all, z=z_all, z_stride=zs, n_samples=S, n_points=W * kw['n_points'])
+            return out, [make_ready(gi, ra, rb) for gi, (ra, rb) in enumerate(cuts)]
+        if pg is not None and zs != 0:
+            self._drop_pregathered()
         if zs == 0:
             g = self._gather_rays(ro, rd).index_select(0, perm)
             z = kw['z']
@@ -318,7 +386,7 @@ class LevelSharding(object):
             z = g[:, 6:].contiguous()
         out.update(rays_o=g[:, 0:3].contiguous(), rays_d=g[:, 3:6].contiguous(), z=z, z_stride=zs, n_samples=S,
                    n_points=W * kw['n_points'])
-        return out
+        return out, None
 
     def encode_exchange_groups(self, table, plan, xh, after_last_start=None):
         """Generator over the plan's groups, in order: yields a group once rows [a, b) of `xh` hold its feature rows.
@@ -327,6 +395,9 @@ class LevelSharding(object):
         the yielded rows follows F, so the all-to-all of group g runs under E(g+1) and the MLP of group g-1."""
         pend = None
         for grp in plan['groups']:
+            if grp.get('ready') is not None:
+                grp['ready']()
+                grp['ready'] = None
             st = self._encode_start(table, grp['kw_all'], grp['m'])
             if after_last_start is not None and grp is plan['groups'][-1]:
                 after_last_start()      # every exchange of this pass is on its way: side work from here delays no wire

@@ -372,6 +372,10 @@ class _ShardedFieldFn(torch.autograd.Function):
                 pipe.count_early(net.encoder.cfg, make_point_src(**plan['kw_all']), plan['count_tag'], dev,
                                  on=pipe.scatter_stream if SHARD_COUNT_STREAM == 'scatter' else None)
             if SHARD_COUNT_AT == 'first':
+                for g_ in plan['groups']:       # (pre-gathered depths: the count pass reads the points of every group)
+                    if g_.get('ready') is not None:
+                        g_['ready']()
+                        g_['ready'] = None
                 count_now()
                 count_now = None
         sigma = torch.empty(M, device=dev, dtype=torch.float32)
@@ -614,8 +618,11 @@ class NeRFNetwork(nn.Module):
         return sigma.reshape(*prefix), {'x_hashtable': xh.reshape(*prefix, -1)}
 
     @torch.no_grad()
-    def density_kw(self, src_kwargs, want_features=False):
-        """density() on a point source given as make_point_src keyword arguments."""
+    def density_kw(self, src_kwargs, want_features=False, per_group=None):
+        """density() on a point source given as make_point_src keyword arguments.
+        per_group(i, group, sigma_rows): level-sharded table with ray groups only -- called as soon as the densities of
+        group i (points [group['a'], group['b']), rays [group['ra'], group['rb'])) exist, while later groups are still on
+        the wire (the renderer resamples the group and starts its depth all-gather there)."""
         if not self._sharded():
             return self.density_src(make_point_src(**src_kwargs), want_features)
         sh = self.level_sharding
@@ -624,11 +631,13 @@ class NeRFNetwork(nn.Module):
         dev = self.encoder.params.device
         xh = torch.empty(M, self.encoder.n_output_dims, device=dev, dtype=torch.float32)
         sigma = torch.empty(M, device=dev, dtype=torch.float32)
-        for grp in sh.encode_exchange_groups(self.encoder.params, plan, xh):
+        for gi, grp in enumerate(sh.encode_exchange_groups(self.encoder.params, plan, xh)):
             a, b = grp['a'], grp['b']
             check(lib().nerf_density_from_features(C.byref(self.encoder.cfg), C.byref(self.net_cfg), ptr(self.sigma_net.params),
                                                    ptr(xh[a:b]), b - a, ptr(sigma[a:b]), stream()),
                   'nerf_density_from_features')
+            if per_group is not None:
+                per_group(gi, grp, sigma[a:b])
         return sigma, (xh if want_features else None)
 
     @torch.no_grad()

@@ -20,6 +20,10 @@ import torch.nn as nn
 from ._lib import check, f32, i64, lib, ptr, stream
 from .nets import NeRFNetwork, make_point_src
 
+# level-sharded table with ray groups: resample and all-gather the fine depths group by group from inside the coarse pass
+# (NerfRenderer._efficient_sampling_by_groups); '0': one all-gather of all depths between the passes
+PIPELINED_DEPTH_GATHER = os.environ.get('NERF_PIPELINED_DEPTH_GATHER', '1') != '0'
+
 
 class _CompositeFn(torch.autograd.Function):
     """renderer.py:71-85 + :181-182 as one kernel, with its hand-written backward."""
@@ -259,6 +263,10 @@ class NerfRenderer(nn.Module):
         N = ro.shape[0]
         zlog_c, z_c = self._coarse_table(ro.device)
         Sc = zlog_c.shape[0]
+        if isinstance(self.model, NeRFNetwork) and PIPELINED_DEPTH_GATHER and self.model._sharded():
+            piped = self._efficient_sampling_by_groups(ro, rd, zlog_c, z_c, n_samples, alpha_const, noise, generator)
+            if piped is not None:
+                return piped
         if isinstance(self.model, NeRFNetwork):
             sigmas, _ = self.model.density_kw(dict(outer_bound=self.outer_bound, rays_o=ro, rays_d=rd, z=z_c, z_stride=0,
                                                    n_samples=Sc, n_points=N * Sc, inner_bound=self.inner_bound,
@@ -284,6 +292,46 @@ class NerfRenderer(nn.Module):
         check(lib().nerf_coarse_to_fine(ptr(sigmas), ptr(zlog_c), 0, ptr(noise), ptr(self._lin_table(n_samples, ro.device)),
                                         N, Sc, n_samples, alpha_const, self._steps_array(self.steps_firstpass),
                                         len(self.steps_firstpass), ptr(zlog_f), ptr(z_f), stream()), 'nerf_coarse_to_fine')
+        return zlog_f, z_f
+
+    def _efficient_sampling_by_groups(self, ro, rd, zlog_c, z_c, n_samples, alpha_const, noise, generator):
+        """efficient_sampling under a level-sharded table with ray groups: group g is resampled as soon as its coarse
+        densities exist and the all-gather of its rays + fine depths (which the fine pass's level owners need) starts at
+        once, under the coarse pass of group g + 1 -- instead of ONE all-gather of all depths standing between the two
+        passes for its whole latency (level_parallel.LevelSharding.pregather_*).  Same depths as the ungrouped form: the
+        in-kernel noise is indexed by the ray's position in the batch (nerf_coarse_to_fine_rng_at).  None when the batch is
+        not cut into the same groups in both passes."""
+        sh = self.model.level_sharding
+        N, Sc = ro.shape[0], zlog_c.shape[0]
+        cuts = sh.cuts_for(N, N * n_samples)
+        if len(cuts) < 2 or cuts != sh.cuts_for(N, N * Sc):
+            return None
+        zlog_f = torch.empty(N, n_samples, device=ro.device)
+        z_f = torch.empty(N, n_samples, device=ro.device)
+        lin = self._lin_table(n_samples, ro.device)
+        steps, n_seg = self._steps_array(self.steps_firstpass), len(self.steps_firstpass)
+        if noise is None:
+            seed, counter = self._noise_stream(generator)
+        else:
+            noise = f32(noise)
+        st = sh.pregather_start(N, cuts)
+
+        def per_group(gi, grp, sig):
+            ra, rb = grp['ra'], grp['rb']
+            assert (ra, rb) == tuple(cuts[gi])
+            if noise is None:
+                check(lib().nerf_coarse_to_fine_rng_at(ptr(sig), ptr(zlog_c), 0, seed, counter, ra, ptr(lin), rb - ra, Sc,
+                                                       n_samples, alpha_const, steps, n_seg, ptr(zlog_f[ra:rb]), ptr(z_f[ra:rb]),
+                                                       stream()), 'nerf_coarse_to_fine_rng_at')
+            else:
+                check(lib().nerf_coarse_to_fine(ptr(sig), ptr(zlog_c), 0, ptr(noise[ra:rb]), ptr(lin), rb - ra, Sc, n_samples,
+                                                alpha_const, steps, n_seg, ptr(zlog_f[ra:rb]), ptr(z_f[ra:rb]), stream()),
+                      'nerf_coarse_to_fine')
+            sh.pregather_group(st, gi, ro[ra:rb], rd[ra:rb], z_f[ra:rb])
+
+        self.model.density_kw(dict(outer_bound=self.outer_bound, rays_o=ro, rays_d=rd, z=z_c, z_stride=0, n_samples=Sc,
+                                   n_points=N * Sc, inner_bound=self.inner_bound, **self._ray_block(N)), per_group=per_group)
+        sh.pregather_finish(st, z_f)
         return zlog_f, z_f
 
     def _noise_stream(self, generator=None):

@@ -165,6 +165,8 @@ int main() {
     EXPECT(nerf_coarse_to_fine(T, T, 0, nullptr, T, 8, 480, 128, 0.2f, steps4, 4, T, T, nullptr) == NERF_EINVAL);
     EXPECT(nerf_coarse_to_fine_rng(T, T, 0, 1, 2, T, 8, 481, 128, 0.2f, steps4, 4, T, T, nullptr) == NERF_EINVAL);
     EXPECT(nerf_coarse_to_fine_rng(T, T, 0, 1, 2, T, 0, 480, 128, 0.2f, steps4, 4, T, T, nullptr) == 0);
+    EXPECT(nerf_coarse_to_fine_rng_at(T, T, 0, 1, 2, -1, T, 8, 480, 128, 0.2f, steps4, 4, T, T, nullptr) == NERF_EINVAL);   // first_ray < 0
+    EXPECT(nerf_coarse_to_fine_rng_at(T, T, 0, 1, 2, 100, T, 0, 480, 128, 0.2f, steps4, 4, T, T, nullptr) == 0);
     EXPECT(nerf_uniform_noise(1, 2, -1, T, nullptr) == NERF_EINVAL && nerf_uniform_noise(1, 2, 0, nullptr, nullptr) == 0);
     EXPECT(nerf_composite_fwd(T, T, T, T, T, 8, 0, 0.f, 1.f, T, T, T, T, nullptr) == NERF_EINVAL);
     EXPECT(nerf_composite_fwd(T, T, T, T, T, 8, 128, 0.f, 1.f, T, T, nullptr, T, nullptr) == NERF_EINVAL);

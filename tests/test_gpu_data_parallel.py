@@ -76,6 +76,10 @@ def _train(rank, world, log2_T=15, precision='float32'):
         assert (net.level_sharding is not None) == (os.environ.get('NERF_TABLE_PARALLEL') != '0')
         if net.level_sharding is not None and int(os.environ.get('NERF_SHARD_GROUPS', '1')) != 1:
             assert net.level_sharding.early_reduces == STEPS        # the hook fired once per backward pass
+    if world > 1 and net.level_sharding is not None:
+        # ray groups: every step's fine-pass rays + depths came from the per-group all-gathers started in the coarse pass
+        want = STEPS if int(os.environ.get('NERF_SHARD_GROUPS', '1')) != 1 else 0
+        assert getattr(net.level_sharding, 'pregather_hits', 0) == want, getattr(net.level_sharding, 'pregather_hits', 0)
     if prefetch and net.level_sharding is not None:
         assert net.level_sharding.prefetch_hits == STEPS - 1, getattr(net.level_sharding, 'prefetch_hits', 0)
     if log2_T >= 19 and (world == 1 or net.level_sharding is not None):

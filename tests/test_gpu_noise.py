@@ -46,3 +46,37 @@ def test_in_kernel_noise_equals_explicit_noise():
     assert torch.equal(zs1, zs4) and torch.equal(img1, img4)
     assert not torch.equal(zs1, zs2)
     assert bool((zs1[:, 1:] >= zs1[:, :-1]).all())
+
+
+def test_resampling_a_slice_of_the_batch_draws_the_batch_noise():
+    """nerf_coarse_to_fine_rng_at: rays [first, first + n) of a batch, resampled alone, get the depths one launch over the
+    whole batch gives them, bit for bit (the ray groups of the level-sharded step resample one after the other)."""
+    from nerf_amd._lib import check, lib, ptr, stream
+    from nerf_amd.renderer import NerfRenderer
+    from oracle.ref_cpu import AnalyticField
+    R = NerfRenderer(AnalyticField(), 2, 2.5, [1.6, 4.8], [64], 128, 0.2)
+    N, Sc, Sf = 301, 64, 127                      # odd Sf: the pair draws of the kernel straddle Philox blocks
+    g = torch.Generator().manual_seed(3)
+    sig = (torch.rand(N, Sc, generator=g) * 4).cuda()
+    zlog_c, _ = R._coarse_table(sig.device)
+    lin, steps = R._lin_table(Sf, sig.device), R._steps_array(R.steps_firstpass)
+
+    def run(first, n, at):
+        zl, z = torch.empty(n, Sf, device='cuda'), torch.empty(n, Sf, device='cuda')
+        s = sig[first:first + n]
+        if at:
+            check(lib().nerf_coarse_to_fine_rng_at(ptr(s), ptr(zlog_c), 0, 77, 5, first, ptr(lin), n, Sc, Sf, 0.2, steps, 1, ptr(zl),
+                                                   ptr(z), stream()), 'nerf_coarse_to_fine_rng_at')
+        else:
+            check(lib().nerf_coarse_to_fine_rng(ptr(s), ptr(zlog_c), 0, 77, 5, ptr(lin), n, Sc, Sf, 0.2, steps, 1, ptr(zl), ptr(z),
+                                                stream()), 'nerf_coarse_to_fine_rng')
+        return zl, z
+    whole = run(0, N, False)
+    assert torch.equal(run(0, N, True)[0], whole[0])
+    for first, n in ((0, 100), (100, 101), (201, 100), (300, 1)):
+        part = run(first, n, True)
+        assert torch.equal(part[0], whole[0][first:first + n]) and torch.equal(part[1], whole[1][first:first + n]), (first, n)
+    if N > 100:
+        assert not torch.equal(run(100, 101, False)[0], whole[0][100:201])        # without the offset: other noise
+    assert lib().nerf_coarse_to_fine_rng_at(ptr(sig), ptr(zlog_c), 0, 77, 5, -1, ptr(lin), 4, Sc, Sf, 0.2, steps, 1,
+                                            ptr(whole[0]), ptr(whole[1]), stream()) < 0

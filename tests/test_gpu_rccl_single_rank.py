@@ -45,6 +45,10 @@ def train(shard, cfg="small"):
         opt.step()
     if shard:
         assert net.level_sharding.prefetch_hits == 2, getattr(net.level_sharding, "prefetch_hits", 0)
+        # ray groups: the fine pass's rays + depths were all-gathered group by group from inside the coarse pass
+        # (asynchronous RCCL all-gathers, waited for one by one right before each group's encode)
+        want = 3 if os.environ.get("NERF_SHARD_GROUPS") else 0
+        assert getattr(net.level_sharding, "pregather_hits", 0) == want, getattr(net.level_sharding, "pregather_hits", 0)
     net.sync_table()
     torch.cuda.synchronize()
     return float(loss), [p.detach().clone() for p in (net.encoder.params, net.sigma_net.params, net.color_net.params, net.latent_emb)]
@@ -76,6 +80,24 @@ assert abs(l2 - l1) < 1e-5, (l2, l1)
 for a, b in zip(grouped, sharded):
     assert float(((a - b).abs() > 1e-5).float().mean()) < 0.02
     assert float((a - b).abs().max()) < 4e-2 + 1e-3
+# in-kernel noise: resampling group by group (nerf_coarse_to_fine_rng_at) draws what one launch over the batch draws
+import nerf_amd.renderer as RM
+os.environ["NERF_SHARD_GROUPS"] = "3"
+net_, _ = _make_pair(NET_CFGS["small"])
+R_ = NerfRenderer(net_, 2, 2.5, [1.6, 4.8], [64], 128, 0.2)
+FusedAdam([{"params": list(net_.parameters()), "lr": 1e-3}], betas=(0.9, 0.99), eps=1e-15).attach(net_, shard_levels=True)
+n_, h_, w_2, K_, E_, bg_, _, _ = [t.cuda() for t in _batch(3, 96)]
+seen = []
+for on in (True, False):
+    RM.PIPELINED_DEPTH_GATHER = on
+    torch.manual_seed(7)
+    with torch.no_grad():
+        _, _, _, aux_ = R_.render(n_, h_, w_2, K_, E_, bg_)
+    seen.append((aux_["z_vals"].clone(), aux_["sigmas"].clone()))
+RM.PIPELINED_DEPTH_GATHER = True
+del os.environ["NERF_SHARD_GROUPS"]
+assert getattr(net_.level_sharding, "pregather_hits", 0) == 1
+assert torch.equal(seen[0][0], seen[1][0]) and float((seen[0][1] - seen[1][1]).abs().max()) < 1e-6
 flag = torch.tensor([3.0], dtype=torch.float64, device="cuda")
 w_ = torch.nn.Parameter(torch.ones(4, device="cuda")); w_.grad = torch.full((4,), 2.0, device="cuda")
 parallel.all_reduce_grads([w_], flags=[flag])
