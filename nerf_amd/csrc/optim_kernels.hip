@@ -17,7 +17,8 @@ namespace {
 template <bool ZERO, bool HALF = false>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n, AdamK k,
-                                                   const double* __restrict__ skip, _Float16* __restrict__ ph = nullptr) {
+                                                   const double* __restrict__ skip, uint16_t* __restrict__ ph_ = nullptr) {
+    _Float16* ph = (_Float16*)ph_;      // (rocprofv3 cannot demangle a _Float16* parameter)
     typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
     auto half4 = [](const f4& a) { h16x4 o; o.x = (_Float16)a.x; o.y = (_Float16)a.y; o.z = (_Float16)a.z; o.w = (_Float16)a.w; return o; };
     const int64_t n4 = n >> 2;
@@ -70,7 +71,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
 // fp32 master table -> half-precision gather copy (round to nearest even; the reference's `precision: float16`,
 // nets.py:31-36,49: tinycudann keeps fp32 master parameters and gathers from their fp16 image).  A pure stream:
 // 4 B read + 2 B written per parameter.
-__global__ __launch_bounds__(256) void table_to_half_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, int64_t n) {
+__global__ __launch_bounds__(256) void table_to_half_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst_, int64_t n) {
+    _Float16* dst = (_Float16*)dst_;
     typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
     const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -92,7 +94,7 @@ extern "C" int nerf_table_to_half(const float* table, void* table_f16, int64_t c
     NERF_REQUIRE((((uintptr_t)table) & 15) == 0 && (((uintptr_t)table_f16) & 7) == 0, "table must be 16-byte, its copy 8-byte aligned");
     int64_t nb = ((count >> 2) + 255) / 256;
     nb = nb < 1 ? 1 : (nb > 65536 ? 65536 : nb);
-    table_to_half_kernel<<<(unsigned)nb, 256, 0, (hipStream_t)stream>>>(table, (_Float16*)table_f16, count);
+    table_to_half_kernel<<<(unsigned)nb, 256, 0, (hipStream_t)stream>>>(table, (uint16_t*)table_f16, count);
     return nerf_launch_status("nerf_table_to_half");
 }
 
@@ -111,8 +113,8 @@ static int adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_s
     const unsigned nb = (unsigned)(want < 65536 ? want : 65536);
     hipStream_t st = (hipStream_t)stream;
     if (param_f16) {
-        if (zero_grad) adam_kernel<true, true><<<nb, 256, 0, st>>>(param, grad, exp_avg, exp_avg_sq, count, k, skip_flag, param_f16);
-        else adam_kernel<false, true><<<nb, 256, 0, st>>>(param, grad, exp_avg, exp_avg_sq, count, k, skip_flag, param_f16);
+        if (zero_grad) adam_kernel<true, true><<<nb, 256, 0, st>>>(param, grad, exp_avg, exp_avg_sq, count, k, skip_flag, (uint16_t*)param_f16);
+        else adam_kernel<false, true><<<nb, 256, 0, st>>>(param, grad, exp_avg, exp_avg_sq, count, k, skip_flag, (uint16_t*)param_f16);
     } else if (zero_grad) adam_kernel<true><<<nb, 256, 0, st>>>(param, grad, exp_avg, exp_avg_sq, count, k, skip_flag);
     else adam_kernel<false><<<nb, 256, 0, st>>>(param, grad, exp_avg, exp_avg_sq, count, k, skip_flag);
     return nerf_launch_status("nerf_adam_step");

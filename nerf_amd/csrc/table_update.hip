@@ -368,7 +368,7 @@ __global__ __launch_bounds__(kSplitThreads) void table_update_kernel(GridDev g, 
                                                                      int64_t n_items_level, float* __restrict__ p,
                                                                      float* __restrict__ m, float* __restrict__ v,
                                                                      AdamK k, const double* __restrict__ skip,
-                                                                     _Float16* __restrict__ ph = nullptr) {
+                                                                     uint16_t* __restrict__ ph = nullptr) {   // (_Float16 bits: rocprofv3 cannot demangle a _Float16* parameter)
     static_assert(kSubFloats % (4 * kSplitThreads) == 0, "whole quads per thread");
     __shared__ __attribute__((aligned(16))) float acc[kSubFloats];
     if (skip && *skip != 0.0) return;       // non-finite loss this step (nerf_losses sums[5]): the step is dropped
@@ -674,7 +674,7 @@ static int table_update_binned(const NerfGridCfg* grid, const NerfLevelSet* leve
         if (table_f16)                                                                                                 \
             table_update_kernel<FF, true><<<nb * kSubs, kSplitThreads, 0, st>>>(g, plan, bin_start, item_idx, item_val, \
                                                                                 8 * n_points, table, exp_avg, exp_avg_sq, k, \
-                                                                                skip_flag, table_f16);                  \
+                                                                                skip_flag, (uint16_t*)table_f16);       \
         else                                                                                                           \
             table_update_kernel<FF><<<nb * kSubs, kSplitThreads, 0, st>>>(g, plan, bin_start, item_idx, item_val,      \
                                                                           8 * n_points, table, exp_avg, exp_avg_sq, k, \

@@ -18,10 +18,12 @@ import json
 import re
 
 ENTRY = [
-    (r'field_fwd_kernel<\d, true, false>', 'nerf_field_fwd'),
-    (r'field_fwd_kernel<\d, false, false>', 'nerf_density_fwd'),
-    (r'field_fwd_kernel<\d, true, true>', 'nerf_field_from_features'),
-    (r'field_fwd_kernel<\d, false, true>', 'nerf_density_from_features'),
+    (r'field_fwd_kernel<\d, true, false(, false)?>', 'nerf_field_fwd'),
+    (r'field_fwd_kernel<\d, false, false(, false)?>', 'nerf_density_fwd'),
+    (r'field_fwd_kernel<\d, true, false, true>', 'nerf_field_fwd_f16'),
+    (r'field_fwd_kernel<\d, false, false, true>', 'nerf_density_fwd_f16'),
+    (r'field_fwd_kernel<\d, true, true(, false)?>', 'nerf_field_from_features'),
+    (r'field_fwd_kernel<\d, false, true(, false)?>', 'nerf_density_from_features'),
     (r'field_bwd_kernel', 'nerf_field_bwd'),
     (r'scatter_(small_)?kernel', 'nerf_hashgrid_scatter'),
     (r'encode_levels_kernel', 'nerf_hashgrid_encode_levels'),
