@@ -530,10 +530,6 @@ static int launch_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const floa
     return nerf_launch_status(COLOR ? "nerf_field_fwd" : "nerf_density_fwd");
 }
 
-extern "C" {
-
-}  // extern "C"
-
 template <bool HALF>
 static int density_fwd(const NerfGridCfg* grid, const NerfNetCfg* net, const float* table, const float* sigma_params,
                        const NerfPointSrc* src, float* sigma, float* x_hashtable, void* stream) {
