@@ -31,8 +31,8 @@ from oracle import ref_cpu
 STEPS, ZB, SF, ALPHA, INNER, OUTER = [64], [1.6, 4.8], 128, 0.2, 2, 2.5
 
 
-def net_kwargs(L, T):
-    return dict(encoding_precision='float32', encoding_n_levels=L, encoding_n_features_per_level=2,
+def net_kwargs(L, T, precision='float32'):
+    return dict(encoding_precision=precision, encoding_n_levels=L, encoding_n_features_per_level=2,
                 encoding_log2_hashmap_size=T, geo_feat_dim=15, sigma_hidden_dim=64, sigma_num_layers=2,
                 encoding_dir_precision='float32', encoding_dir_encoding='SphericalHarmonics', encoding_dir_degree=4,
                 latent_embedding_dim=48, color_hidden_dim=64, color_num_layers=3)
@@ -123,16 +123,17 @@ def quality_run(res, n_img, L, T, iters, n_rays):
             'trained_render_rays_per_s_%dx%d_views' % (res, res): render_rps}
 
 
-def delta_run(res, n_img, L, T, iters, n_rays, fused_tail=True):
+def delta_run(res, n_img, L, T, iters, n_rays, fused_tail=True, precision='float32'):
     """HIP vs CPU oracle: identical init, batches, noise, budget.  `fused_tail`: the HIP side takes the route
     Trainer.train_step takes (NerfRenderer.render_loss: compositing + losses in one kernel); False = render() followed by
-    helpers.fused_train_loss.  The result names the table levels that went through the binned update."""
+    helpers.fused_train_loss.  The result names the table levels that went through the binned update.
+    precision 'float16': both sides gather from the fp16 rounding of their fp32 master table (nets.py:31-36)."""
     loader = ProceduralSceneLoader(n_img, res, res, seed=0, batch_seed=1)
     imgs = render_ground_truth(loader, res)
     loader.set_images(imgs)
     imgs_c = imgs.cpu()
-    ora = ref_cpu.OracleNetwork(n_img, seed=0, **net_kwargs(L, T))
-    net = NeRFNetwork(n_img, **net_kwargs(L, T))
+    ora = ref_cpu.OracleNetwork(n_img, seed=0, **net_kwargs(L, T, precision))
+    net = NeRFNetwork(n_img, **net_kwargs(L, T, precision))
     with torch.no_grad():
         net.encoder.params.copy_(ora.encoder_params)
         net.sigma_net.params.copy_(ora.sigma_params)
@@ -180,7 +181,8 @@ def delta_run(res, n_img, L, T, iters, n_rays, fused_tail=True):
     p_o = ref_cpu.psnr(img_o.clamp(0, 1), gtc.cpu())
     p_g = helpers.psnr(img_g.detach().clamp(0, 1), gtc)
     pipe = net.table_pipeline
-    return {'config': 'L%d T%d, %d images %dx%d, %d iters x %d rays, identical init/batches/noise' % (L, T, n_img, res, res, iters, n_rays),
+    return {'config': 'L%d T%d, %d images %dx%d, %d iters x %d rays, identical init/batches/noise' % (L, T, n_img, res, res, iters, n_rays)
+            + ('' if precision == 'float32' else ', table precision ' + precision),
             'binned_levels': list(pipe.binned_levels) if pipe is not None else [], 'fused_tail': bool(fused_tail),
             'skipped_steps': og.skipped_steps, 'psnr_hip': p_g, 'psnr_cpu_oracle': p_o, 'psnr_delta': p_g - p_o,
             'max_abs_loss_diff': max(abs(a - b) for a, b in zip(lg, lo)), 'loss_first': [lg[0], lo[0]], 'loss_last': [lg[-1], lo[-1]],

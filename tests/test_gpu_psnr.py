@@ -34,3 +34,17 @@ def test_psnr_delta_on_the_binned_table_update():
     assert r['psnr_hip'] > 13.0, r
     assert abs(r['psnr_delta']) <= 0.05, r
     assert r['max_abs_loss_diff'] <= 5e-4, r
+
+
+def test_psnr_delta_with_the_half_precision_table():
+    """`precision: float16` (tests/test_gpu_half_table.py): the same comparison with both sides gathering from the fp16 image
+    of their fp32 master table, the HIP side's image written by the binned update pass itself.  Bar: 0.05 dB."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import psnr_run
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    r = psnr_run.delta_run(res=64, n_img=20, L=20, T=19, iters=30, n_rays=1024, precision='float16')
+    assert len(r['binned_levels']) >= 8 and 'float16' in r['config'], r
+    assert r['skipped_steps'] == 0, r
+    assert r['psnr_hip'] > 12.0, r
+    assert abs(r['psnr_delta']) <= 0.05, r
+    assert r['max_abs_loss_diff'] <= 5e-4, r
