@@ -282,6 +282,29 @@ def _exchange_worker(rank, world, port, q, grid='fake7'):
                and torch.equal(plan['groups'][1]['kw_all']['rays_o'][:, 0], want_o[world * 3:])
                and torch.equal(plan['groups'][1]['kw_local']['n'], torch.arange(3, 5))
                and torch.equal(plan['groups'][1]['kw_local']['z'], z[3:5]))
+    # the same plan from rows all-gathered group by group BEFOREHAND (pregather_*: what the renderer does from inside the
+    # coarse pass, so that the fine pass's plan() issues no collective): identical group-major source, filled per group
+    cuts = sh.cuts_for(R, R * S, groups=2)
+    st = sh.pregather_start(R, cuts)
+    for gi, (ra, rb) in enumerate(cuts):
+        sh.pregather_group(st, gi, ro[ra:rb], (-ro)[ra:rb], z[ra:rb])
+    sh.pregather_finish(st, z)
+    plan2 = sh.plan(kw, groups=2)
+    ok_pre = cuts == [(0, 3), (3, 5)] and all(g['ready'] is not None for g in plan2['groups'])
+    for g in plan2['groups']:
+        g['ready']()
+    ok_pre = (ok_pre and getattr(sh, 'pregather_hits', 0) == 1 and sh._pregathered is None
+              and all(torch.equal(plan2['kw_all'][k], plan['kw_all'][k]) for k in ('rays_o', 'rays_d', 'z'))
+              and torch.equal(plan2['groups'][1]['kw_all']['z'], plan['groups'][1]['kw_all']['z']))
+    # ... and a plan for ANOTHER depth tensor must not pick them up (they are waited for and dropped)
+    st = sh.pregather_start(R, cuts)
+    for gi, (ra, rb) in enumerate(cuts):
+        sh.pregather_group(st, gi, ro[ra:rb], (-ro)[ra:rb], z[ra:rb])
+    sh.pregather_finish(st, z)
+    plan3 = sh.plan(dict(kw, z=z.clone()), groups=2)
+    ok_pre = (ok_pre and all(g['ready'] is None for g in plan3['groups']) and sh.pregather_hits == 1 and sh._pregathered is None
+              and torch.equal(plan3['kw_all']['z'], plan['kw_all']['z']))
+    ok_plan = ok_plan and ok_pre
     # backward data movement of the groups: value = 1000 rank + 100 point + 10 level + f at point p = ray * S + k
     dfeat = torch.tensor([[val(rank, p, l, f) for l in range(L) for f in range(F)] for p in range(R * S)])
     state = None
