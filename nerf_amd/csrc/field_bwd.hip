@@ -462,7 +462,10 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s_i
         }
         // d(loss)/d(features) goes to HBM as [point][L*F]; the table scatter is a separate,
         // atomic-bound launch with its own lane mapping (see scatter_kernel in field_fwd.hip)
-        if (valid) {
+#ifndef NERF_BWD_ABL_NO_DFEAT      // (timing ablation, tools/ab builds only: what the strided stores of d(features) cost)
+#define NERF_BWD_ABL_NO_DFEAT 0
+#endif
+        if (valid && !(NERF_BWD_ABL_NO_DFEAT && x0[0] != 12345.678f)) {
             float* dst = dfeat + p * LF + h * LHF;
             if (vec) {      // this lane's LHF gradients are 16-byte aligned and contiguous: 16-byte stores
                 f32x4* d4 = (f32x4*)dst;
