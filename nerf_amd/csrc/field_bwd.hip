@@ -107,6 +107,21 @@ __device__ __forceinline__ f32x16 dw_tile(f32x16 acc, const float* SA, const flo
 }
 #endif
 
+// The barriers of the tile loop order LDS traffic only (the staging buffers SA / SB).  __syncthreads() also waits for vmcnt(0),
+// i.e. for every global load in flight (the next tile's inputs, requested a tile ahead; the latent / feature rows re-read for
+// staging); an LDS-only barrier (s_waitcnt lgkmcnt(0) + s_barrier, -DNERF_BWD_LDS_BARRIER=1) measured the same, 0.503 vs
+// 0.503 ms on one box: those loads have landed by the time a barrier is reached.  The plain form stays.
+#ifndef NERF_BWD_LDS_BARRIER
+#define NERF_BWD_LDS_BARRIER 0
+#endif
+__device__ __forceinline__ void lds_barrier() {
+#if NERF_BWD_LDS_BARRIER
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+    __syncthreads();
+#endif
+}
+
 // stage a 64-row P-layout activation pair as [unit][point]
 __device__ __forceinline__ void stage64(float* S, int col, int h, const f32x16& v0, const f32x16& v1) {
 #pragma unroll
@@ -303,24 +318,24 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s_i
             d3[1] = dr1 * r1 * (1.f - r1);
             d3[2] = dr2 * r2 * (1.f - r2);
         }
-        __syncthreads();  // previous iteration's readers of SA/SB are done
+        lds_barrier();  // previous iteration's readers of SA/SB are done
         if (h == 0) {
             SA[0 * kSP + col] = STG(d3[0]);
             SA[1 * kSP + col] = STG(d3[1]);
             SA[2 * kSP + col] = STG(d3[2]);
         }
         stage64(SB, col, h, e0, e1);
-        __syncthreads();
+        lds_barrier();
         if (wave >= 2) acc_y = dw_tile(acc_y, SA, SB, 0, wave - 2, 3, kHid, l31, h);
         f32x16 g0, g1;
         layer_T_Nx64<3, kPC3>(lds + kWC3, 3, l31, h, d3, g0, g1);
         g0 = relu_mask(g0, e0);
         g1 = relu_mask(g1, e1);
         // ------------------------- colour layer 2 -------------------------
-        __syncthreads();
+        lds_barrier();
         stage64(SA, col, h, g0, g1);
         stage64(SB, col, h, c0, c1);
-        __syncthreads();
+        lds_barrier();
         float lat2[24];
         load_latent_half(lat2, lrow, s.lat_half);      // lands under the dW MFMAs below
         if (!n_ok) {
@@ -335,7 +350,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s_i
             g1 = relu_mask(t1, c1);
         }
         // ------------------------- colour layer 1 -------------------------
-        __syncthreads();
+        lds_barrier();
         stage64(SA, col, h, g0, g1);
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -357,7 +372,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s_i
 #pragma unroll
         for (int t = 0; t < 24; ++t)
             if (t < s.lat_half) SB[(15 + s.sh_dim + h * s.lat_half + t) * kSP + col] = STG(lat2[t]);
-        __syncthreads();
+        lds_barrier();
         acc_c1 = dw_tile(acc_c1, SA, SB, wave / in_c_tiles, wave % in_c_tiles, kHid, s.in_c, l31, h);
         if (wave < 2 && 4 + wave < 2 * in_c_tiles)
             acc_x = dw_tile(acc_x, SA, SB, (4 + wave) / in_c_tiles, (4 + wave) % in_c_tiles, kHid, s.in_c, l31, h);
@@ -418,11 +433,11 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s_i
 #pragma unroll
         for (int t = 0; t < 8; ++t) d2[t] = dG[t];
         if (h == 0) d2[0] = o2[0] > 0.f ? dsig : 0.f;
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int t = 0; t < 8; ++t) SA[(krow(t) + 4 * h) * kSP + col] = STG(d2[t]);
         stage64(SB, col, h, a0, a1);
-        __syncthreads();
+        lds_barrier();
         float xf2[XF];
         load_features<XF>(xf2, xrow, LHF, LF, h, vec);
         if (wave < 2) acc_y = dw_tile(acc_y, SA, SB, 0, wave, kGeoRows, kHid, l31, h);
@@ -430,12 +445,12 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(GridDev g, NetLds s_i
         g0 = relu_mask(g0, a0);
         g1 = relu_mask(g1, a1);
         // ------------------------- sigma layer 1 -------------------------
-        __syncthreads();
+        lds_barrier();
         stage64(SA, col, h, g0, g1);
 #pragma unroll
         for (int t = 0; t < XF; ++t)
             if (t < LHF) SB[(h * LHF + t) * kSP + col] = STG(xf2[t]);
-        __syncthreads();
+        lds_barrier();
         acc_s1 = dw_tile(acc_s1, SA, SB, wave >> 1, wave & 1, kHid, s.in_sp, l31, h);
 #if NERF_BWD_XF_PREFETCH == 2
         // the next tile's feature half row is requested HERE, late in the tile (its registers are free only now): it lands
